@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s + ms/frame of the DOGERAY render path on MI355X.
+
+Workload (BASELINE.json metric; config "highpoly.rts (~1M tris) 1920x1080"): the reference scene is a
+missing blob, so the stand-in SURVEY.md 8(d) specifies is generated: a 709x709-vertex heightfield
+(1 002 528 triangles, 38-column .rts, smooth normals, materials {0,3,5}), 1920x1080, 1 spp per frame,
+depth 10.  A "step" is one full frame = one launch of the megakernel over every pixel.  A "ray" is one
+closest-hit query (one hit() call, kernel.cu K:800).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+N > 1 is launched by torch.distributed.run, one rank per GPU; the framebuffer is tiled by interleaved
+8-pixel block columns and gathered to rank 0 over RCCL every --gather-every frames (scaling: strong,
+the frame is fixed).  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def ensure_scene(cache_dir, verts, W, H):
+    path = os.path.join(cache_dir, "heightfield_%d_%dx%d.rts" % (verts, W, H))
+    if not os.path.exists(path):
+        os.makedirs(cache_dir, exist_ok=True)
+        gen = os.path.join(ROOT, "tools", "scenegen")
+        if not os.path.exists(gen):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", gen, gen + ".cpp"])
+        tmp = path + ".tmp%d" % os.getpid()
+        subprocess.check_call([gen, "heightfield", tmp, str(verts), str(W), str(H)])
+        os.replace(tmp, path)
+    return path
+
+
+def algorithmic_bytes(c, frames, W, H):
+    """32 B per node visit, 36 B per triangle test, 128 B per shaded hit, 4 B per texel,
+    12 B per pixel written per frame."""
+    return 32 * c["node_visits"] + 36 * c["prim_tests"] + 128 * c["shades"] + 4 * c["texels"] + 12 * W * H * frames
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--verts", type=int, default=709, help="heightfield vertices per side (709 -> 1 002 528 triangles)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--traversal", choices=["threaded", "ordered"], default="ordered")
+    ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-col-mod", type=int, default=4, help="cpu_baseline renders every n-th block column")
+    ap.add_argument("--cache", default=os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"))
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            log("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
+            sys.exit(2)
+        args.gpus = world
+
+    import torch
+    import dogeray_amd as dr
+    from dogeray_amd import multigpu
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    W, H = args.width, args.height
+    t0 = time.time()
+    if rank == 0:
+        scene_path = ensure_scene(args.cache, args.verts, W, H)
+    if dist is not None:
+        dist.barrier()
+    scene_path = ensure_scene(args.cache, args.verts, W, H)
+    scene = dr.Scene.load(scene_path, "")
+    t_parse = time.time() - t0
+    t0 = time.time()
+    scene.build_bvh()
+    t_bvh = time.time() - t0
+    s = scene.settings()
+    ntris = scene.num_objects
+    ctx = dr.Context(local_rank)
+    t0 = time.time()
+    ctx.upload(scene)
+    t_upload = time.time() - t0
+    mode = dr.TRAVERSAL_ORDERED if args.traversal == "ordered" else dr.TRAVERSAL_THREADED
+    ctx.set_traversal(mode)
+    ctx.set_stripe(world, rank)
+    st = dr.pack_settings13(s, 1, spp=1)
+    if rank == 0:
+        log("scene %s: %d triangles, parse %.1fs, BVH %.1fs, upload %.2fs" % (os.path.basename(scene_path), ntris, t_parse, t_bvh, t_upload))
+
+    seed_base, seed_stride = 1, 1000003
+    ctx.accum_reset(W, H)
+    acc = multigpu.accumulator_tensor(ctx, torch.device("cuda", local_rank)) if world > 1 else None
+
+    def run_frames(first, count):
+        """Render frames [first, first+count) into the accumulator; gather every --gather-every frames."""
+        k = 0
+        while k < count:
+            n = min(args.gather_every, count - k) if world > 1 else count - k
+            ctx.render_accumulate(st, W, H, s.background, seed_base + (first + k) * seed_stride, seed_stride, n)
+            if world > 1:
+                multigpu.gather_frame(acc, W, H, world, rank)
+            k += n
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- warmup, then the timed region
+    run_frames(0, args.warmup)
+    ctx.stats_reset()
+    fence()
+    t0 = time.perf_counter()
+    run_frames(args.warmup, args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timed = ctx.stats()
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- untimed: count what the timed frames traced (same seeds -> same paths)
+    ctx.enable_counters(True)
+    ctx.stats_reset()
+    ctx.accum_reset(W, H)
+    ctx.render_accumulate(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, args.steps)
+    own = ctx.stats()
+    ref_order = own
+    if mode != dr.TRAVERSAL_THREADED:
+        # algorithmic bytes are defined on the reference's traversal order: count that too
+        ctx.set_traversal(dr.TRAVERSAL_THREADED)
+        ctx.stats_reset()
+        ctx.accum_reset(W, H)
+        ctx.render_accumulate(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, args.steps)
+        ref_order = ctx.stats()
+        ctx.set_traversal(mode)
+    ctx.enable_counters(False)
+    rays_local = own["rays"]
+    rays = rays_local
+    if dist is not None:
+        rt = torch.tensor([rays_local], dtype=torch.int64, device="cuda")
+        dist.all_reduce(rt)
+        rays = int(rt.item())
+
+    if rank != 0:
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    frames = args.steps
+    kernel_ms = timed["kernel_ms"] / max(1, timed["frames"])          # HIP events on the render stream, rank 0
+    abytes = algorithmic_bytes(ref_order, frames, W if world == 1 else W // world, H) / frames
+    kbytes = algorithmic_bytes(own, frames, W if world == 1 else W // world, H) / frames
+    achieved = abytes / (kernel_ms * 1e-3) / 1e9
+    result = {
+        "metric": "Mrays/sec + ms/frame, 1M-tri .rts at 1920x1080",
+        "value": rays / elapsed / 1e6,
+        "unit": "Mrays/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / frames * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": "C4 stand-in for samples/highpoly.rts: heightfield %d triangles, %dx%d, 1 spp/frame, depth %d, %s traversal"
+                        % (ntris, W, H, s.max_depth, args.traversal),
+            "triangles": ntris, "width": W, "height": H, "spp_per_frame": 1, "max_depth": int(s.max_depth),
+            "frames": frames, "parallelism": "framebuffer block-column stripes x%d" % world,
+            "gather_every": args.gather_every if world > 1 else None,
+        },
+        "rays_per_frame": rays / frames,
+        "primary_samples_per_s": (W * H * frames) / elapsed,
+        "kernel_ms_per_frame": kernel_ms,
+        "per_ray": {
+            "reference_order": {"V": ref_order["node_visits"] / ref_order["rays"], "L": ref_order["prim_tests"] / ref_order["rays"],
+                                "S": ref_order["shades"] / ref_order["rays"], "T": ref_order["texels"] / ref_order["rays"],
+                                "bytes": abytes * frames / ref_order["rays"]},
+            "kernel": {"V": own["node_visits"] / own["rays"], "L": own["prim_tests"] / own["rays"],
+                       "bytes": kbytes * frames / own["rays"]},
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "algorithmic_bytes_per_launch": abytes,
+            "kernel_own_visit_bytes_per_launch": kbytes,
+            "launch_ms": kernel_ms,
+            "note": "algorithmic bytes use the reference traversal's visit counts (SURVEY 8(d)); kernel_own_* uses this kernel's own counts",
+        },
+        "setup_s": {"parse": t_parse, "bvh_build": t_bvh, "upload": t_upload},
+    }
+
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import orc
+            ncpu = os.cpu_count() or 1
+            t0 = time.time()
+            osc = orc.Scene(scene_path)
+            osc.build_bvh()
+            t_setup = time.time() - t0
+            t0 = time.perf_counter()
+            img, c = osc.render(st, W, H, s.background, seed_base + args.warmup * seed_stride, nthreads=ncpu,
+                                col_mod=args.cpu_col_mod, col_rem=0)
+            dt = time.perf_counter() - t0
+            # parity spot check on the sampled block columns against the GPU's first timed frame
+            ctx.accum_reset(W, H)
+            ctx.render_accumulate(st, W, H, s.background, seed_base + args.warmup * seed_stride, 0, 1)
+            gpu = ctx.accum_read()
+            import numpy as np
+            cols = (np.arange(W) // 8) % args.cpu_col_mod == 0
+            same = float(np.all(gpu[cols] == img[cols], axis=2).mean())
+            result["cpu_baseline"] = {
+                "value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": ncpu, "kind": "port",
+                "sample": "oracle (oracle/dogeray_oracle.cpp), %d std::threads, every %d-th 8-pixel block column of one %dx%d frame "
+                          "of the same scene/seed: %d rays in %.2f s (+%.1f s oracle parse+BVH, not timed)"
+                          % (ncpu, args.cpu_col_mod, W, H, c["rays"], dt, t_setup),
+                "pixels_identical_to_gpu_on_sample": same,
+            }
+        except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
+            result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    print(json.dumps(result), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,376 @@
+"""dogeray_amd -- MI355X-native render path for DOGERAY scenes.
+
+Thin ctypes binding of libdogeray_amd.so (C ABI in include/dogeray_amd.h).  All rendering
+happens in the HIP library; there is no Python or CPU fallback: if the shared library is
+missing or no GPU is present the calls below raise.
+
+The Python surface mirrors the reference's host flow (kernel.cu main(), K:2021-2557):
+    Scene.load(path, texture_dir)   ~ getnum + getppm* + read            (K:2055-2071)
+    scene.build_bvh()               ~ build_bvh                          (K:2091)
+    Context(device).upload(scene)   ~ what CudaStarter re-uploads per frame (K:2618-2629)
+    ctx.render_frame(settings13, ...)  ~ CudaStarter(outputr, ..., divisor) (K:2562)
+    ProgressiveRenderer             ~ the present loop's preview ladder + accumulation (K:2154-2224)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libdogeray_amd.so")
+
+TRAVERSAL_THREADED = 0
+TRAVERSAL_ORDERED = 1
+
+
+class DogerayError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("dogeray_amd error %d: %s" % (code, msg))
+        self.code = code
+
+
+class DrObject(C.Structure):
+    _fields_ = [("type", C.c_int32), ("pos", C.c_float * 3), ("rot", C.c_float * 3), ("norm", C.c_float * 3),
+                ("n1", C.c_float * 3), ("n2", C.c_float * 3), ("n3", C.c_float * 3), ("t1", C.c_float * 3),
+                ("t2", C.c_float * 3), ("t3", C.c_float * 3), ("smooth", C.c_int32), ("tex", C.c_int32),
+                ("mat", C.c_int32), ("dim", C.c_float * 3), ("col", C.c_float * 3), ("texnum", C.c_int32),
+                ("rtexnum", C.c_int32), ("addional", C.c_float * 3)]
+
+
+OBJECT_DTYPE = np.dtype([("type", "<i4"), ("pos", "<f4", 3), ("rot", "<f4", 3), ("norm", "<f4", 3),
+                         ("n1", "<f4", 3), ("n2", "<f4", 3), ("n3", "<f4", 3), ("t1", "<f4", 3), ("t2", "<f4", 3),
+                         ("t3", "<f4", 3), ("smooth", "<i4"), ("tex", "<i4"), ("mat", "<i4"), ("dim", "<f4", 3),
+                         ("col", "<f4", 3), ("texnum", "<i4"), ("rtexnum", "<i4"), ("addional", "<f4", 3)])
+BVH_DTYPE = np.dtype([("active", "<i4"), ("children", "<i4", 2), ("count", "<i4"), ("hit_node", "<i4"),
+                      ("miss_node", "<i4"), ("under", "<i4"), ("min", "<f4", 3), ("max", "<f4", 3), ("end", "<i4")])
+
+
+class DrSettings(C.Structure):
+    _fields_ = [("campos", C.c_float * 3), ("look", C.c_float * 3), ("aperture", C.c_float),
+                ("focus_dist", C.c_float), ("fov", C.c_int32), ("max_depth", C.c_int32), ("spp", C.c_int32),
+                ("background", C.c_float), ("backtex", C.c_int32), ("width", C.c_int32), ("height", C.c_int32)]
+
+
+class DrStats(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("samples", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64),
+                ("prim_tests", C.c_uint64), ("shades", C.c_uint64), ("texels", C.c_uint64), ("kernel_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/dogeray_amd.h declares: (name, restype, argtypes)
+_VP = C.c_void_p
+_API = [
+    ("dr_last_error", C.c_char_p, []),
+    ("dr_abi_version", C.c_int, []),
+    ("dr_scene_load", C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_VP)]),
+    ("dr_scene_free", None, [_VP]),
+    ("dr_scene_num_objects", C.c_int, [_VP]),
+    ("dr_scene_get_objects", C.c_int, [_VP, _VP]),
+    ("dr_scene_get_settings", C.c_int, [_VP, C.POINTER(DrSettings)]),
+    ("dr_scene_set_settings", C.c_int, [_VP, C.POINTER(DrSettings)]),
+    ("dr_scene_num_textures", C.c_int, [_VP]),
+    ("dr_scene_texture_info", C.c_int, [_VP, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("dr_scene_texture_data", C.c_int, [_VP, C.c_int, _VP]),
+    ("dr_scene_build_bvh", C.c_int, [_VP, C.c_int]),
+    ("dr_scene_bvh_size", C.c_int, [_VP]),
+    ("dr_scene_bvh_used", C.c_int, [_VP]),
+    ("dr_scene_get_bvh", C.c_int, [_VP, _VP]),
+    ("dr_device_count", C.c_int, []),
+    ("dr_context_create", C.c_int, [C.c_int, C.POINTER(_VP)]),
+    ("dr_context_destroy", None, [_VP]),
+    ("dr_context_upload_scene", C.c_int, [_VP, _VP]),
+    ("dr_context_set_stripe", C.c_int, [_VP, C.c_int, C.c_int]),
+    ("dr_context_set_traversal", C.c_int, [_VP, C.c_int]),
+    ("dr_render_frame", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, _VP]),
+    ("dr_accum_reset", C.c_int, [_VP, C.c_int, C.c_int]),
+    ("dr_render_accumulate", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_int]),
+    ("dr_accum_read", C.c_int, [_VP, _VP]),
+    ("dr_accum_present", C.c_int, [_VP, C.c_int, _VP]),
+    ("dr_accum_device_ptr", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
+    ("dr_stats_enable_counters", C.c_int, [_VP, C.c_int]),
+    ("dr_stats_reset", C.c_int, [_VP]),
+    ("dr_stats_get", C.c_int, [_VP, C.POINTER(DrStats)]),
+    ("dr_kat_rng", C.c_int, [_VP, C.c_uint64, C.c_int, _VP]),
+    ("dr_kat_aabb", C.c_int, [_VP, C.c_int] + [_VP] * 6),
+    ("dr_kat_tri", C.c_int, [_VP, C.c_int] + [_VP] * 6),
+    ("dr_kat_sphere", C.c_int, [_VP, C.c_int] + [_VP] * 5),
+    ("dr_kat_optics", C.c_int, [_VP, C.c_int] + [_VP] * 6),
+    ("dr_kat_hit", C.c_int, [_VP, C.c_int] + [_VP] * 4),
+]
+API_SYMBOLS = [a[0] for a in _API]
+
+_lib = None
+
+
+def lib():
+    """The loaded libdogeray_amd.so.  Raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError("libdogeray_amd.so is missing: run `python -m dogeray_amd.build` "
+                              "(or __graft_entry__.build()); dogeray_amd has no fallback path")
+        L = C.CDLL(_LIB_PATH)
+        for name, res, args in _API:
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise DogerayError(rc, lib().dr_last_error().decode(errors="replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def device_count():
+    return lib().dr_device_count()
+
+
+def pack_settings13(s, divisor, spp=None, depth=None):
+    """float settings[13] exactly as CudaStarter packs it (K:2581)."""
+    return np.array([s.campos[0], s.campos[1], s.campos[2], s.look[0], s.look[1], s.look[2], s.aperture,
+                     s.focus_dist, s.fov, s.max_depth if depth is None else depth, s.spp if spp is None else spp,
+                     divisor, s.backtex], dtype=np.float32)
+
+
+class Scene:
+    """Host scene: objects, settings, textures, BVH (allobjects / nbvhtree / globals of the reference)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def load(cls, rts_path, texture_dir=""):
+        """texture_dir: directory scanned for *ppm* entries; None = process cwd (reference behaviour),
+        "" = none."""
+        h = _VP()
+        td = None if texture_dir is None else os.fsencode(texture_dir)
+        _check(lib().dr_scene_load(os.fsencode(rts_path), td, C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            lib().dr_scene_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def num_objects(self):
+        return lib().dr_scene_num_objects(self._h)
+
+    def objects(self):
+        out = np.zeros(self.num_objects + 1, dtype=OBJECT_DTYPE)
+        _check(lib().dr_scene_get_objects(self._h, _p(out)))
+        return out
+
+    def settings(self):
+        s = DrSettings()
+        _check(lib().dr_scene_get_settings(self._h, C.byref(s)))
+        return s
+
+    def set_settings(self, s):
+        _check(lib().dr_scene_set_settings(self._h, C.byref(s)))
+
+    def textures(self):
+        res = []
+        for i in range(lib().dr_scene_num_textures(self._h)):
+            w, h = C.c_int(), C.c_int()
+            _check(lib().dr_scene_texture_info(self._h, i, C.byref(w), C.byref(h)))
+            a = np.zeros((h.value, w.value, 4), dtype=np.uint8)
+            _check(lib().dr_scene_texture_data(self._h, i, _p(a)))
+            res.append(a)
+        return res
+
+    def build_bvh(self, nthreads=0):
+        _check(lib().dr_scene_build_bvh(self._h, nthreads))
+
+    def bvh(self):
+        n = lib().dr_scene_bvh_size(self._h)
+        out = np.zeros(n, dtype=BVH_DTYPE)
+        _check(lib().dr_scene_get_bvh(self._h, _p(out)))
+        return out, lib().dr_scene_bvh_used(self._h)
+
+
+class Context:
+    """One GPU with a resident scene; render_frame() is the CudaStarter replacement."""
+
+    def __init__(self, device=0):
+        h = _VP()
+        _check(lib().dr_context_create(device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().dr_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene):
+        _check(lib().dr_context_upload_scene(self._h, scene._h))
+        return self
+
+    def set_stripe(self, mod, rem):
+        _check(lib().dr_context_set_stripe(self._h, mod, rem))
+
+    def set_traversal(self, mode):
+        _check(lib().dr_context_set_traversal(self._h, mode))
+
+    def render_frame(self, settings13, W, H, background, frame_seed, download=True):
+        """Returns int32[W, H, 3] indexed [x, y] (the reference's column-major int3 buffer) or None."""
+        st = _f32(settings13)
+        assert st.shape == (13,)
+        out = np.empty((W, H, 3), dtype=np.int32) if download else None
+        _check(lib().dr_render_frame(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1),
+                                     _p(out) if download else None))
+        return out
+
+    def accum_reset(self, W, H):
+        _check(lib().dr_accum_reset(self._h, W, H))
+        self._acc_shape = (W, H, 3)
+
+    def render_accumulate(self, settings13, W, H, background, frame_seed, seed_stride, nframes):
+        st = _f32(settings13)
+        _check(lib().dr_render_accumulate(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1),
+                                          int(seed_stride) & (2 ** 64 - 1), nframes))
+
+    def accum_read(self):
+        out = np.empty(self._acc_shape, dtype=np.int32)
+        _check(lib().dr_accum_read(self._h, _p(out)))
+        return out
+
+    def accum_present(self, divide_by):
+        """uint8[H, W, 3] row-major image: clamp(acc / divide_by, 0, 255) (K:2287)."""
+        W, H, _ = self._acc_shape
+        out = np.empty((H, W, 3), dtype=np.uint8)
+        _check(lib().dr_accum_present(self._h, divide_by, _p(out)))
+        return out
+
+    def accum_device_ptr(self):
+        p, n = _VP(), C.c_uint64()
+        _check(lib().dr_accum_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def enable_counters(self, on=True):
+        _check(lib().dr_stats_enable_counters(self._h, 1 if on else 0))
+
+    def stats_reset(self):
+        _check(lib().dr_stats_reset(self._h))
+
+    def stats(self):
+        s = DrStats()
+        _check(lib().dr_stats_get(self._h, C.byref(s)))
+        return s.as_dict()
+
+    # ---- known-answer hooks (tests)
+    def kat_rng(self, seed, n):
+        out = np.zeros(n, dtype=np.float64)
+        _check(lib().dr_kat_rng(self._h, seed, n, _p(out)))
+        return out
+
+    def kat_aabb(self, o, d, mn, mx):
+        o, d, mn, mx = map(_f32, (o, d, mn, mx))
+        n = o.shape[0]
+        hit = np.zeros(n, dtype=np.int32)
+        dist = np.zeros(n, dtype=np.float32)
+        _check(lib().dr_kat_aabb(self._h, n, _p(o), _p(d), _p(mn), _p(mx), _p(hit), _p(dist)))
+        return hit, dist
+
+    def kat_tri(self, o, d, v0, v1, v2):
+        o, d, v0, v1, v2 = map(_f32, (o, d, v0, v1, v2))
+        n = o.shape[0]
+        t = np.zeros(n, dtype=np.float32)
+        _check(lib().dr_kat_tri(self._h, n, _p(o), _p(d), _p(v0), _p(v1), _p(v2), _p(t)))
+        return t
+
+    def kat_sphere(self, o, d, c, r):
+        o, d, c, r = map(_f32, (o, d, c, r))
+        n = o.shape[0]
+        t = np.zeros(n, dtype=np.float32)
+        _check(lib().dr_kat_sphere(self._h, n, _p(o), _p(d), _p(c), _p(r), _p(t)))
+        return t
+
+    def kat_optics(self, v, nrm, eta):
+        v, nrm, eta = map(_f32, (v, nrm, eta))
+        n = v.shape[0]
+        refl = np.zeros((n, 3), dtype=np.float32)
+        refr = np.zeros((n, 3), dtype=np.float32)
+        sch = np.zeros(n, dtype=np.float32)
+        _check(lib().dr_kat_optics(self._h, n, _p(v), _p(nrm), _p(eta), _p(refl), _p(refr), _p(sch)))
+        return refl, refr, sch
+
+    def kat_hit(self, o, d):
+        o, d = _f32(o), _f32(d)
+        n = o.shape[0]
+        t = np.zeros(n, dtype=np.float32)
+        idx = np.zeros(n, dtype=np.int32)
+        _check(lib().dr_kat_hit(self._h, n, _p(o), _p(d), _p(t), _p(idx)))
+        return t, idx
+
+
+class ProgressiveRenderer:
+    """The present loop's render schedule (kernel.cu K:2154-2224), headless.
+
+    iter 0..3: preview ladder at 1/8, 1/4, 1/2, 1/1 resolution into `outr` (iter 0 with the
+    file's spp/depth, iter 1..3 with spp 1 / depth 2); iter >= 4: full-resolution frames with the
+    file's spp/depth added to `outr`.  The displayed value is clamp(outr / (iter - pnum), 0, 255)
+    with integer division (K:2287).  frame k uses seed seed_base + k * seed_stride.
+    """
+
+    LADDER = (8, 4, 2, 1)
+
+    def __init__(self, ctx, scene_settings, seed_base=1, seed_stride=1000003):
+        self.ctx = ctx
+        self.s = scene_settings
+        self.W, self.H = scene_settings.width, scene_settings.height
+        self.seed_base, self.seed_stride = seed_base, seed_stride
+        self.iter = 0
+        self.frames_rendered = 0
+        self.ctx.accum_reset(self.W, self.H)
+
+    def _seed(self):
+        return self.seed_base + self.frames_rendered * self.seed_stride
+
+    def step(self):
+        """One present-loop iteration.  Returns (td, divide_by) for display."""
+        s, c = self.s, self.ctx
+        if self.iter < 4:
+            div = self.LADDER[self.iter]
+            spp, depth = (s.spp, s.max_depth) if self.iter == 0 else (1, 2)
+            st = pack_settings13(s, div, spp=spp, depth=depth)
+            c.accum_reset(self.W, self.H)           # CudaStarter overwrites outr on these calls
+            c.render_accumulate(st, self.W, self.H, s.background, self._seed(), 0, 1)
+            pnum = self.iter
+            td = div
+        else:
+            st = pack_settings13(s, 1)
+            c.render_accumulate(st, self.W, self.H, s.background, self._seed(), 0, 1)
+            pnum = 3
+            td = 1
+        self.frames_rendered += 1
+        self.iter += 1
+        return td, self.iter - pnum
+
+    def image(self, divide_by):
+        return self.ctx.accum_present(divide_by)

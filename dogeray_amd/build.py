@@ -1,0 +1,58 @@
+"""Builds libdogeray_amd.so (HIP kernels for gfx950 + host C++ + the C ABI) in-tree with hipcc."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libdogeray_amd.so")
+HOST_SOURCES = ["rts_reader.cpp", "bvh_builder.cpp", "linearise.cpp", "capi_host.cpp"]
+DEVICE_SOURCES = ["context.hip"]
+# -ffp-contract=off: no FMA contraction on host or device -- the BVH build and the kernel's
+# arithmetic are specified operation by operation (DESIGN.md "arithmetic contract").
+COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra",
+          "-Wno-unused-parameter", "-pthread"]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if p and (os.path.isabs(p) and os.path.exists(p) or not os.path.isabs(p)):
+            return p
+    return "hipcc"
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".hpp"))]
+    headers.append(os.path.join(HERE, "..", "include", "dogeray_amd.h"))
+    objs = []
+    hipcc = _hipcc()
+    os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    for src in HOST_SOURCES + DEVICE_SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(HERE, "_build", src + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [sp] + headers + [os.path.abspath(__file__)]):
+            cmd = [hipcc] + COMMON + ["--offload-arch=" + ARCH, "-c", sp, "-o", obj]
+            if src.endswith(".cpp"):
+                cmd = [hipcc] + COMMON + ["-x", "c++", "-c", sp, "-o", obj]
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+    if force or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-pthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,571 @@
+// Device context: resident scene, render launches, on-device accumulation, stats, KAT hooks.
+// Replaces CudaStarter (kernel.cu K:2562-2669), which mallocs, uploads the whole scene,
+// launches, synchronises, downloads and frees on every call.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_core.hpp"
+#include "linearise.hpp"
+#include "scene_host.hpp"
+
+namespace dr {
+
+// ------------------------------------------------------------------ kernels
+// One wave = one 8x8 pixel tile, as in the reference launch (K:2634-2640: block (8,8)); four
+// tiles per 256-thread workgroup.  Tiles are numbered column-major over the block columns this
+// context owns, so neighbouring waves work on vertically adjacent tiles (coherent rays, and the
+// column-major framebuffer gives each wave eight 96-byte runs).
+template <bool COUNT, int MODE>
+__global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
+  __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : 1];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * 4 + wave;
+  Ctr c = {0, 0, 0, 0, 0, 0};
+  if (tile < P.ncols * P.gy) {
+    const int col = tile / P.gy, by = tile - col * P.gy;
+    const int bx = P.stripe_rem + col * P.stripe_mod;
+    const int x = bx * 8 + (lane >> 3), y = by * 8 + (lane & 7);
+    if (MODE == DR_TRAVERSAL_ORDERED) {
+      int* stack = lds_stack + wave * (ORDERED_STACK * 64) + lane;
+      auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_ordered<COUNT>(P.pairs, P.prims, o, d, cc, stack); };
+      render_pixel<COUNT>(P, closest, x, y, c);
+    } else {
+      auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_threaded<COUNT>(P.nodes, P.prims, o, d, cc); };
+      render_pixel<COUNT>(P, closest, x, y, c);
+    }
+  }
+  if (COUNT) {
+    unsigned v[6] = {c.rays, c.V, c.L, c.S, c.T, c.samples};
+    for (int k = 0; k < 6; k++) {
+      unsigned long long s = v[k];
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (lane == 0 && s) atomicAdd(&P.counters[k], s);
+    }
+  }
+}
+
+__global__ void zero_rect_kernel(int32_t* out, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) out[i] = 0;
+}
+
+// clamp(acc / divide_by, 0, 255) into row-major RGB8 (draw loop K:2281-2287)
+__global__ void present_kernel(const int32_t* acc, uint8_t* rgb, int W, int H, int div) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= W * H) return;
+  int x = idx / H, y = idx - x * H;          // consecutive threads walk a column (coalesced read)
+  const int32_t* p = acc + (size_t)idx * 3;
+  uint8_t* q = rgb + ((size_t)y * W + x) * 3;
+  for (int k = 0; k < 3; k++) {
+    int v = p[k] / div;
+    v = v < 0 ? 0 : (v > 255 ? 255 : v);
+    q[k] = (uint8_t)v;
+  }
+}
+
+// ---- known-answer kernels
+__global__ void kat_rng_kernel(uint64_t seed, int n, double* out) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    Xorwow r; r.init(seed);
+    for (int i = 0; i < n; i++) out[i] = r.uniform_double();
+  }
+}
+__global__ void kat_aabb_kernel(int n, const float* o, const float* d, const float* mn, const float* mx, int32_t* hit, float* dist) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3 dd = ld3(d + 3 * i);
+  V3 inv = mk(1.0f / dd.x, 1.0f / dd.y, 1.0f / dd.z);
+  float t;
+  bool h = slab(ld3(o + 3 * i), inv, mn + 3 * i, mx + 3 * i, t);
+  hit[i] = h; dist[i] = h ? t : 0;
+}
+__global__ void kat_tri_kernel(int n, const float* o, const float* d, const float* v0, const float* v1, const float* v2, float* t) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3 a = ld3(v0 + 3 * i);
+  t[i] = tri_hit(ld3(o + 3 * i), ld3(d + 3 * i), a, ld3(v1 + 3 * i) - a, ld3(v2 + 3 * i) - a);
+}
+__global__ void kat_sphere_kernel(int n, const float* o, const float* d, const float* c, const float* r, float* t) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  t[i] = sphere_hit(ld3(c + 3 * i), r[i], ld3(o + 3 * i), ld3(d + 3 * i));
+}
+__global__ void kat_optics_kernel(int n, const float* v, const float* nrm, const float* eta, float* refl, float* refr, float* sch) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  V3 a = ld3(v + 3 * i), b = ld3(nrm + 3 * i);
+  V3 r1 = reflect(a, b), r2 = refract(a, b, eta[i]);
+  refl[3 * i] = r1.x; refl[3 * i + 1] = r1.y; refl[3 * i + 2] = r1.z;
+  refr[3 * i] = r2.x; refr[3 * i + 1] = r2.y; refr[3 * i + 2] = r2.z;
+  sch[i] = reflectance(a.x, eta[i]);
+}
+template <int MODE>
+__global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, const float* o, const float* d, float* t, int32_t* slot) {
+  __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : 1];
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Ctr c = {0, 0, 0, 0, 0, 0};
+  Hit h;
+  if (MODE == DR_TRAVERSAL_ORDERED) {
+    int* stack = lds_stack + (threadIdx.x >> 6) * (ORDERED_STACK * 64) + (threadIdx.x & 63);
+    h = closest_hit_ordered<false>(P.pairs, P.prims, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
+  } else {
+    h = closest_hit_threaded<false>(P.nodes, P.prims, ld3(o + 3 * i), ld3(d + 3 * i), c);
+  }
+  t[i] = h.t; slot[i] = h.slot;
+}
+
+}  // namespace dr
+
+// ------------------------------------------------------------------ context
+using namespace dr;
+
+struct dr_context {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // resident scene
+  DevNode* nodes = nullptr;
+  DevPair* pairs = nullptr;
+  DevPrim* prims = nullptr;
+  DevShade* shade = nullptr;
+  DevTex* tex = nullptr;
+  uint32_t* texels = nullptr;
+  int n_prims = 0, n_tex = 0, tree_depth = 0;
+  std::vector<int> slot_to_orig;
+  // frame + accumulator
+  int32_t* frame = nullptr; size_t frame_elems = 0;
+  int32_t* accum = nullptr; size_t accum_elems = 0; int accW = 0, accH = 0;
+  uint8_t* present = nullptr; size_t present_bytes = 0;
+  unsigned long long* counters = nullptr;
+  int stripe_mod = 1, stripe_rem = 0;
+  int traversal = DR_TRAVERSAL_THREADED;
+  bool count = false;
+  dr_stats stats;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                      \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                        \
+      return DR_ERR_DEVICE;                                                                \
+    }                                                                                      \
+  } while (0)
+
+template <class T>
+int upload(T*& dst, const std::vector<T>& src) {
+  if (dst) { (void)hipFree(dst); dst = nullptr; }
+  size_t bytes = src.size() * sizeof(T);
+  if (bytes == 0) bytes = sizeof(T);
+  HIP_TRY(hipMalloc((void**)&dst, bytes));
+  if (!src.empty()) HIP_TRY(hipMemcpy(dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+  return DR_OK;
+}
+
+int ensure(int32_t*& buf, size_t& have, size_t need) {
+  if (have >= need && buf) return DR_OK;
+  if (buf) { (void)hipFree(buf); buf = nullptr; have = 0; }
+  HIP_TRY(hipMalloc((void**)&buf, need * sizeof(int32_t)));
+  have = need;
+  return DR_OK;
+}
+
+struct V3h { float x, y, z; };
+inline V3h hsub(V3h a, V3h b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline V3h hmul(V3h a, V3h b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline V3h hdiv(V3h a, V3h b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline V3h hsplat(float a) { return {a, a, a}; }
+inline float hdot(V3h a, V3h b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline V3h hcross(V3h a, V3h b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+inline V3h hnorm(V3h v) { float inv = 1.0f / sqrtf(hdot(v, v)); return {v.x * inv, v.y * inv, v.z * inv}; }
+inline void st3(float* d, V3h v) { d[0] = v.x; d[1] = v.y; d[2] = v.z; }
+inline int hf2i(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)f;
+}
+
+// settings[13] -> per-launch constants.  The camera block is K:1016-1052, evaluated once on the
+// host (it is identical for every pixel) with the reference's float/double promotions.
+int make_params(dr_context* c, const float* st, int W, int H, float background, uint64_t seed, RenderParams& P) {
+  if (!c->nodes) { set_error("no scene uploaded"); return DR_ERR_INVALID; }
+  if (W <= 0 || H <= 0 || (size_t)W * (size_t)H > (size_t)1 << 28) { set_error("bad frame size"); return DR_ERR_INVALID; }
+  const int div = hf2i(st[11]);
+  if (div < 1) { set_error("divisor must be >= 1"); return DR_ERR_INVALID; }
+  const int backtex = hf2i(st[12]);
+  if (backtex >= c->n_tex) { set_error("backtex refers to a texture that is not loaded"); return DR_ERR_INVALID; }
+  memset(&P, 0, sizeof(P));
+  P.nodes = c->nodes; P.pairs = c->pairs; P.prims = c->prims; P.shade = c->shade; P.tex = c->tex; P.texels = c->texels;
+  P.counters = c->counters;
+  float aspect = float(W / st[11]) / float(H / st[11]);           // K:1016 (int / float)
+  float fov = (float)((double)st[8] * M_PI / 180);                // K:1020
+  float vh = (float)(2.0 * (double)tanf(fov / 2));                // K:1023
+  float vw = aspect * vh;
+  V3h from = {st[0], st[1], st[2]}, at = {st[3], st[4], st[5]};
+  float focus = st[7];
+  V3h vup = {0, 1, 0};
+  V3h wu = hnorm(hsub(from, at));
+  V3h uu = hnorm(hcross(vup, wu));
+  V3h vu = hcross(wu, uu);
+  V3h hor = hmul(hmul(hsplat(focus), hsplat(vw)), uu);            // K:1047
+  V3h ver = hmul(hmul(hsplat(focus), hsplat(vh)), vu);
+  V3h llc = hsub(hsub(hsub(from, hdiv(hor, hsplat(2))), hdiv(ver, hsplat(2))), hmul(hsplat(focus), wu));
+  st3(P.from, from); st3(P.llc, llc); st3(P.hor, hor); st3(P.ver, ver); st3(P.uu, uu); st3(P.vu, vu);
+  P.lens_radius = st[6] / 2;                                      // K:1052
+  P.bgint = background;
+  P.spp_f = st[10];
+  P.scale = (float)(1.0 / (double)st[10]);                        // K:1081
+  P.den_w = (double)float(W / st[11]);                            // K:1067
+  P.den_h = (double)float(H / st[11]);
+  P.seed = seed;
+  P.W = W; P.H = H;
+  P.gx = W / div / 8; P.gy = H / div / 8;                         // K:2636
+  P.stripe_mod = c->stripe_mod; P.stripe_rem = c->stripe_rem;
+  P.ncols = P.gx > c->stripe_rem ? (P.gx - c->stripe_rem + c->stripe_mod - 1) / c->stripe_mod : 0;
+  P.seed_stride = 8u * (unsigned)P.gx;                            // blockDim.x * gridDim.x, K:1065
+  P.max_depth = hf2i(st[9]);
+  P.backtex = backtex;
+  return DR_OK;
+}
+
+int launch_render(dr_context* c, const RenderParams& P) {
+  int tiles = P.ncols * P.gy;
+  if (tiles <= 0) return DR_OK;
+  dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  const bool ordered = c->traversal == DR_TRAVERSAL_ORDERED;
+  if (c->count) {
+    if (ordered) hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P);
+    else hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P);
+  } else {
+    if (ordered) hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P);
+    else hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P);
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  return DR_OK;
+}
+
+int collect_time(dr_context* c, uint64_t frames, uint64_t samples) {
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  c->stats.kernel_ms += ms;
+  c->stats.frames += frames;
+  c->stats.samples += samples;
+  return DR_OK;
+}
+
+template <class T>
+struct DevBuf {
+  T* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t n) { HIP_TRY(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T))); return DR_OK; }
+  int put(const T* src, size_t n) { HIP_TRY(hipMemcpy(p, src, n * sizeof(T), hipMemcpyHostToDevice)); return DR_OK; }
+  int get(T* dst, size_t n) { HIP_TRY(hipMemcpy(dst, p, n * sizeof(T), hipMemcpyDeviceToHost)); return DR_OK; }
+};
+
+}  // namespace
+
+extern "C" {
+
+int dr_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int dr_context_create(int device_ordinal, dr_context** out) {
+  if (!out) { set_error("out is null"); return DR_ERR_INVALID; }
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device (this library has no CPU fallback)"); return DR_ERR_DEVICE; }
+  if (device_ordinal < 0 || device_ordinal >= n) { set_error("device ordinal out of range"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(device_ordinal));
+  dr_context* c = new dr_context();
+  c->device = device_ordinal;
+  memset(&c->stats, 0, sizeof(c->stats));
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+      hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void**)&c->counters, 6 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->counters, 0, 6 * sizeof(unsigned long long)) != hipSuccess) {
+    set_error("cannot create stream/events");
+    dr_context_destroy(c);
+    return DR_ERR_DEVICE;
+  }
+  *out = c;
+  return DR_OK;
+}
+
+void dr_context_destroy(dr_context* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  void* bufs[] = {c->nodes, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters};
+  for (void* b : bufs) if (b) (void)hipFree(b);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+int dr_context_upload_scene(dr_context* c, const dr_scene* s) {
+  if (!c || !s) { set_error("null argument"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  DeviceImage img;
+  int rc = linearise(s->host, img);
+  if (rc != DR_OK) return rc;
+  if ((rc = upload(c->nodes, img.nodes)) != DR_OK) return rc;
+  if ((rc = upload(c->pairs, img.pairs)) != DR_OK) return rc;
+  if ((rc = upload(c->prims, img.prims)) != DR_OK) return rc;
+  if ((rc = upload(c->shade, img.shade)) != DR_OK) return rc;
+  if ((rc = upload(c->tex, img.tex)) != DR_OK) return rc;
+  if ((rc = upload(c->texels, img.texels)) != DR_OK) return rc;
+  c->n_prims = (int)img.prims.size();
+  c->n_tex = (int)img.tex.size();
+  c->slot_to_orig = img.slot_to_orig;
+  int depth = 0;
+  while (((size_t)1 << depth) < img.prims.size()) depth++;
+  c->tree_depth = depth;
+  return DR_OK;
+}
+
+int dr_context_set_stripe(dr_context* c, int mod, int rem) {
+  if (!c || mod < 1 || rem < 0 || rem >= mod) { set_error("stripe: need mod >= 1 and 0 <= rem < mod"); return DR_ERR_INVALID; }
+  c->stripe_mod = mod; c->stripe_rem = rem;
+  return DR_OK;
+}
+
+int dr_context_set_traversal(dr_context* c, int mode) {
+  if (!c || (mode != DR_TRAVERSAL_THREADED && mode != DR_TRAVERSAL_ORDERED)) { set_error("unknown traversal mode"); return DR_ERR_INVALID; }
+  if (mode == DR_TRAVERSAL_ORDERED && c->nodes && c->tree_depth > ORDERED_STACK) {
+    set_error("ordered traversal supports at most 2^24 primitives");
+    return DR_ERR_SCENE;
+  }
+  c->traversal = mode;
+  return DR_OK;
+}
+
+int dr_render_frame(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
+                    int32_t* out_int3) {
+  if (!c || !settings13) { set_error("null argument"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  RenderParams P;
+  int rc = make_params(c, settings13, W, H, background, frame_seed, P);
+  if (rc != DR_OK) return rc;
+  if (c->traversal == DR_TRAVERSAL_ORDERED && c->tree_depth > ORDERED_STACK) { set_error("tree too deep for ordered traversal"); return DR_ERR_SCENE; }
+  size_t elems = (size_t)W * H * 3;
+  if ((rc = ensure(c->frame, c->frame_elems, elems)) != DR_OK) return rc;
+  HIP_TRY(hipMemsetAsync(c->frame, 0, elems * sizeof(int32_t), c->stream));   // unrendered margins are 0
+  P.out = c->frame;
+  P.accumulate = 0;
+  if ((rc = launch_render(c, P)) != DR_OK) return rc;
+  uint64_t samples = (uint64_t)P.ncols * P.gy * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0);
+  if ((rc = collect_time(c, 1, samples)) != DR_OK) return rc;
+  if (out_int3) {
+    HIP_TRY(hipMemcpyAsync(out_int3, c->frame, elems * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DR_OK;
+}
+
+int dr_accum_reset(dr_context* c, int W, int H) {
+  if (!c || W <= 0 || H <= 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  size_t elems = (size_t)W * H * 3;
+  int rc = ensure(c->accum, c->accum_elems, elems);
+  if (rc != DR_OK) return rc;
+  c->accW = W; c->accH = H;
+  HIP_TRY(hipMemsetAsync(c->accum, 0, elems * sizeof(int32_t), c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DR_OK;
+}
+
+int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
+                         uint64_t seed_stride, int nframes) {
+  if (!c || !settings13 || nframes < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  if (!c->accum || c->accW != W || c->accH != H) { set_error("call dr_accum_reset(W, H) first"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  if (nframes == 0) return DR_OK;
+  RenderParams P;
+  int rc = make_params(c, settings13, W, H, background, frame_seed, P);
+  if (rc != DR_OK) return rc;
+  if (c->traversal == DR_TRAVERSAL_ORDERED && c->tree_depth > ORDERED_STACK) { set_error("tree too deep for ordered traversal"); return DR_ERR_SCENE; }
+  P.out = c->accum;
+  P.accumulate = 1;
+  int tiles = P.ncols * P.gy;
+  if (tiles <= 0) return DR_OK;
+  dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+  const bool ordered = c->traversal == DR_TRAVERSAL_ORDERED;
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  for (int k = 0; k < nframes; k++) {
+    P.seed = frame_seed + (uint64_t)k * seed_stride;
+    if (c->count) {
+      if (ordered) hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P);
+      else hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P);
+    } else {
+      if (ordered) hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P);
+      else hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  uint64_t samples = (uint64_t)tiles * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0) * (uint64_t)nframes;
+  if ((rc = collect_time(c, (uint64_t)nframes, samples)) != DR_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DR_OK;
+}
+
+int dr_accum_read(dr_context* c, int32_t* out_int3) {
+  if (!c || !out_int3 || !c->accum) { set_error("no accumulator"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemcpyAsync(out_int3, c->accum, (size_t)c->accW * c->accH * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DR_OK;
+}
+
+int dr_accum_present(dr_context* c, int divide_by, uint8_t* out_rgb8) {
+  if (!c || !out_rgb8 || !c->accum || divide_by == 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  size_t bytes = (size_t)c->accW * c->accH * 3;
+  if (c->present_bytes < bytes) {
+    if (c->present) (void)hipFree(c->present);
+    c->present = nullptr; c->present_bytes = 0;
+    HIP_TRY(hipMalloc((void**)&c->present, bytes));
+    c->present_bytes = bytes;
+  }
+  int n = c->accW * c->accH;
+  hipLaunchKernelGGL(present_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, c->accum, c->present, c->accW, c->accH, divide_by);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(out_rgb8, c->present, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DR_OK;
+}
+
+int dr_accum_device_ptr(dr_context* c, void** dev_ptr, uint64_t* bytes) {
+  if (!c || !dev_ptr || !c->accum) { set_error("no accumulator"); return DR_ERR_INVALID; }
+  *dev_ptr = c->accum;
+  if (bytes) *bytes = (uint64_t)c->accW * c->accH * 3 * sizeof(int32_t);
+  return DR_OK;
+}
+
+int dr_stats_enable_counters(dr_context* c, int on) {
+  if (!c) { set_error("null context"); return DR_ERR_INVALID; }
+  c->count = on != 0;
+  return DR_OK;
+}
+
+int dr_stats_reset(dr_context* c) {
+  if (!c) { set_error("null context"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  HIP_TRY(hipMemset(c->counters, 0, 6 * sizeof(unsigned long long)));
+  memset(&c->stats, 0, sizeof(c->stats));
+  return DR_OK;
+}
+
+int dr_stats_get(dr_context* c, dr_stats* out) {
+  if (!c || !out) { set_error("null argument"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  unsigned long long h[6];
+  HIP_TRY(hipMemcpy(h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
+  *out = c->stats;
+  out->rays = h[0]; out->node_visits = h[1]; out->prim_tests = h[2]; out->shades = h[3]; out->texels = h[4];
+  if (c->count) out->samples = h[5];
+  return DR_OK;
+}
+
+// ---- KAT hooks
+#define KAT_PRE(n)                                                        \
+  if (!c || (n) < 0) { set_error("bad argument"); return DR_ERR_INVALID; } \
+  HIP_TRY(hipSetDevice(c->device));                                        \
+  if ((n) == 0) return DR_OK;                                              \
+  int rc_ = DR_OK;                                                         \
+  (void)rc_;
+#define KAT_DO(expr) if ((rc_ = (expr)) != DR_OK) return rc_
+
+int dr_kat_rng(dr_context* c, uint64_t seed, int n, double* out) {
+  KAT_PRE(n);
+  DevBuf<double> d; KAT_DO(d.alloc((size_t)n));
+  hipLaunchKernelGGL(kat_rng_kernel, dim3(1), dim3(64), 0, c->stream, seed, n, d.p);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return d.get(out, (size_t)n);
+}
+
+int dr_kat_aabb(dr_context* c, int n, const float* o, const float* d, const float* mn, const float* mx, int32_t* hit, float* dist) {
+  KAT_PRE(n);
+  DevBuf<float> bo, bd, bmn, bmx, bdist; DevBuf<int32_t> bhit;
+  size_t m = (size_t)n * 3;
+  KAT_DO(bo.alloc(m)); KAT_DO(bd.alloc(m)); KAT_DO(bmn.alloc(m)); KAT_DO(bmx.alloc(m)); KAT_DO(bdist.alloc((size_t)n)); KAT_DO(bhit.alloc((size_t)n));
+  KAT_DO(bo.put(o, m)); KAT_DO(bd.put(d, m)); KAT_DO(bmn.put(mn, m)); KAT_DO(bmx.put(mx, m));
+  hipLaunchKernelGGL(kat_aabb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, bo.p, bd.p, bmn.p, bmx.p, bhit.p, bdist.p);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  KAT_DO(bhit.get(hit, (size_t)n));
+  return bdist.get(dist, (size_t)n);
+}
+
+int dr_kat_tri(dr_context* c, int n, const float* o, const float* d, const float* v0, const float* v1, const float* v2, float* t) {
+  KAT_PRE(n);
+  DevBuf<float> bo, bd, b0, b1, b2, bt;
+  size_t m = (size_t)n * 3;
+  KAT_DO(bo.alloc(m)); KAT_DO(bd.alloc(m)); KAT_DO(b0.alloc(m)); KAT_DO(b1.alloc(m)); KAT_DO(b2.alloc(m)); KAT_DO(bt.alloc((size_t)n));
+  KAT_DO(bo.put(o, m)); KAT_DO(bd.put(d, m)); KAT_DO(b0.put(v0, m)); KAT_DO(b1.put(v1, m)); KAT_DO(b2.put(v2, m));
+  hipLaunchKernelGGL(kat_tri_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, bo.p, bd.p, b0.p, b1.p, b2.p, bt.p);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return bt.get(t, (size_t)n);
+}
+
+int dr_kat_sphere(dr_context* c, int n, const float* o, const float* d, const float* centre, const float* radius, float* t) {
+  KAT_PRE(n);
+  DevBuf<float> bo, bd, bc, br, bt;
+  size_t m = (size_t)n * 3;
+  KAT_DO(bo.alloc(m)); KAT_DO(bd.alloc(m)); KAT_DO(bc.alloc(m)); KAT_DO(br.alloc((size_t)n)); KAT_DO(bt.alloc((size_t)n));
+  KAT_DO(bo.put(o, m)); KAT_DO(bd.put(d, m)); KAT_DO(bc.put(centre, m)); KAT_DO(br.put(radius, (size_t)n));
+  hipLaunchKernelGGL(kat_sphere_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, bo.p, bd.p, bc.p, br.p, bt.p);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return bt.get(t, (size_t)n);
+}
+
+int dr_kat_optics(dr_context* c, int n, const float* v, const float* nrm, const float* eta, float* refl, float* refr, float* schlick) {
+  KAT_PRE(n);
+  DevBuf<float> bv, bn, be, b1, b2, b3;
+  size_t m = (size_t)n * 3;
+  KAT_DO(bv.alloc(m)); KAT_DO(bn.alloc(m)); KAT_DO(be.alloc((size_t)n)); KAT_DO(b1.alloc(m)); KAT_DO(b2.alloc(m)); KAT_DO(b3.alloc((size_t)n));
+  KAT_DO(bv.put(v, m)); KAT_DO(bn.put(nrm, m)); KAT_DO(be.put(eta, (size_t)n));
+  hipLaunchKernelGGL(kat_optics_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, n, bv.p, bn.p, be.p, b1.p, b2.p, b3.p);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  KAT_DO(b1.get(refl, m)); KAT_DO(b2.get(refr, m));
+  return b3.get(schlick, (size_t)n);
+}
+
+int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx) {
+  KAT_PRE(n);
+  if (!c->nodes) { set_error("no scene uploaded"); return DR_ERR_INVALID; }
+  DevBuf<float> bo, bd, bt; DevBuf<int32_t> bs;
+  size_t m = (size_t)n * 3;
+  KAT_DO(bo.alloc(m)); KAT_DO(bd.alloc(m)); KAT_DO(bt.alloc((size_t)n)); KAT_DO(bs.alloc((size_t)n));
+  KAT_DO(bo.put(o, m)); KAT_DO(bd.put(d, m));
+  RenderParams P;
+  memset(&P, 0, sizeof(P));
+  P.nodes = c->nodes; P.pairs = c->pairs; P.prims = c->prims;
+  dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  if (c->traversal == DR_TRAVERSAL_ORDERED) hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p);
+  else hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  KAT_DO(bt.get(t, (size_t)n));
+  std::vector<int32_t> slots((size_t)n);
+  KAT_DO(bs.get(slots.data(), (size_t)n));
+  for (int i = 0; i < n; i++) idx[i] = slots[(size_t)i] >= 0 ? c->slot_to_orig[(size_t)slots[(size_t)i]] : 0;   // hit() returns index 0 on a miss (K:507)
+  return DR_OK;
+}
+
+}  // extern "C"

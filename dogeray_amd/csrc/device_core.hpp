@@ -1,0 +1,469 @@
+// Device functions of the path-tracing megakernel (gfx950).
+//
+// Each function states which reference function it replaces (kernel.cu, K:<line>).  The
+// arithmetic (operation order, float/double promotion, comparison direction) follows the
+// reference expression by expression, because a one-ulp difference flips hit/miss branches
+// and rejection loops; what changes is where operands come from (SoA records, per-ray
+// precomputation) and how lanes are scheduled.  Build with -ffp-contract=off: no FMA
+// contraction, IEEE division and square root.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_layout.h"
+
+namespace dr {
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float a, float b, float c) { V3 r; r.x = a; r.y = b; r.z = c; return r; }
+__device__ __forceinline__ V3 splat(float a) { return mk(a, a, a); }
+__device__ __forceinline__ V3 ld3(const float* p) { return mk(p[0], p[1], p[2]); }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator/(V3 a, V3 b) { return mk(a.x / b.x, a.y / b.y, a.z / b.z); }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 a, V3 b) {
+  return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ float length(V3 a) { return __builtin_sqrtf(dot(a, a)); }
+__device__ __forceinline__ V3 normalized(V3 v) {              // getNormalizedVec K:179
+  float inv = 1.0f / __builtin_sqrtf(dot(v, v));
+  return mk(v.x * inv, v.y * inv, v.z * inv);
+}
+
+// float -> int as CUDA's cvt.rzi.s32.f32: saturating, NaN -> 0 (K:802,1083-1085)
+__device__ __forceinline__ int f2i(float f) {
+  if (f != f) return 0;
+  if (f >= 2147483648.0f) return 2147483647;
+  if (f <= -2147483648.0f) return (-2147483647 - 1);
+  return (int)f;
+}
+
+// ------------------------------------------------------------------ RNG: cuRAND XORWOW
+// curand_init(seed, 0, 0) / curand() / curand_uniform_double() (call sites K:644,657,1065-1068)
+struct Xorwow {
+  uint32_t v0, v1, v2, v3, v4, d;
+  __device__ __forceinline__ void init(uint64_t seed) {
+    uint32_t s0 = (uint32_t)seed ^ 0xaad26b49u;
+    uint32_t s1 = (uint32_t)(seed >> 32) ^ 0xf7dcefddu;
+    uint32_t t0 = 1099087573u * s0;
+    uint32_t t1 = 2591861531u * s1;
+    d = 6615241u + t1 + t0;
+    v0 = 123456789u + t0;
+    v1 = 362436069u ^ t0;
+    v2 = 521288629u + t1;
+    v3 = 88675123u ^ t1;
+    v4 = 5783321u + t0;
+  }
+  __device__ __forceinline__ uint32_t next() {
+    uint32_t t = v0 ^ (v0 >> 2);
+    v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+    v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1));
+    d += 362437u;
+    return v4 + d;
+  }
+  __device__ __forceinline__ double uniform_double() {
+    uint32_t x = next(), y = next();
+    uint64_t z = (uint64_t)x ^ ((uint64_t)y << 21);
+    return (double)z * 1.1102230246251565e-16 + 5.5511151231257827e-17;
+  }
+};
+
+__device__ __forceinline__ V3 rand_in_unit_sphere(Xorwow& r) {   // K:640-648
+  for (;;) {
+    float x = (float)(r.uniform_double() * 2 - 1);
+    float y = (float)(r.uniform_double() * 2 - 1);
+    float z = (float)(r.uniform_double() * 2 - 1);
+    V3 p = mk(x, y, z);
+    float l = length(p);
+    if (l * l >= 1) continue;                                     // pow(len, 2.0f)
+    return p;
+  }
+}
+__device__ __forceinline__ float randy(Xorwow& r) { return (float)r.uniform_double(); }   // K:651
+__device__ __forceinline__ V3 rand_in_unit_disk(Xorwow& r) {     // K:988-994
+  for (;;) {
+    float x = randy(r) * 2 - 1;
+    float y = randy(r) * 2 - 1;
+    V3 p = mk(x, y, 0);
+    float l = length(p);
+    if (l * l >= 1) continue;
+    return p;
+  }
+}
+
+// ------------------------------------------------------------------ intersection
+// aabb2 K:244-274 with the reciprocal direction hoisted out of the node loop (same divide,
+// same operands) and the per-axis early return folded into one final comparison: t_min only
+// grows, t_max only shrinks and neither can become NaN, so "t_max <= t_min after some axis"
+// and "t_max <= t_min after the last axis" are the same predicate.
+__device__ __forceinline__ bool slab(V3 o, V3 inv, const float mn[3], const float mx[3], float& dist) {
+  float t_min = 0, t_max = 10000;
+  {
+    float t0 = (mn[0] - o.x) * inv.x, t1 = (mx[0] - o.x) * inv.x;
+    if (inv.x < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+  }
+  {
+    float t0 = (mn[1] - o.y) * inv.y, t1 = (mx[1] - o.y) * inv.y;
+    if (inv.y < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+  }
+  {
+    float t0 = (mn[2] - o.z) * inv.z, t1 = (mx[2] - o.z) * inv.z;
+    if (inv.z < 0.0f) { float s = t0; t0 = t1; t1 = s; }
+    t_min = t0 > t_min ? t0 : t_min;
+    t_max = t1 < t_max ? t1 : t_max;
+  }
+  dist = t_min;
+  return t_max > t_min;
+}
+
+// hit_tri K:277-313 on {v0, e1 = v1 - v0, e2 = v2 - v0}; returns t or -1.
+// 1.0/a is a double division narrowed to float in the reference; narrowing a correctly
+// rounded double quotient of two floats equals the correctly rounded float quotient.
+__device__ __forceinline__ float tri_hit(V3 ro, V3 rd, V3 v0, V3 e1, V3 e2) {
+  const float EPS = 0.0001f;
+  V3 h = cross(rd, e2);
+  float a = dot(e1, h);
+  if (a > -EPS && a < EPS) return -1.0f;
+  float f = 1.0f / a;
+  V3 s = ro - v0;
+  float u = f * dot(s, h);
+  if (u < 0.0f || u > 1.0f) return -1.0f;
+  V3 q = cross(s, e1);
+  float v = f * dot(rd, q);
+  if (v < 0.0f || u + v > 1.0f) return -1.0f;
+  float t = f * dot(e2, q);
+  return t > EPS ? t : -1.0f;
+}
+
+// hit_sphere K:316-333
+__device__ __forceinline__ float sphere_hit(V3 c, float radius, V3 o, V3 d) {
+  V3 oc = o - c;
+  float ld = length(d);
+  float a = ld * ld;
+  float half_b = dot(oc, d);
+  float lo = length(oc);
+  float cc = lo * lo - radius * radius;
+  float disc = half_b * half_b - a * cc;
+  if (disc < 0) return -1.0f;
+  return (-half_b - __builtin_sqrtf(disc)) / a;
+}
+
+// singlehit K:432-464 on one DevPrim; returns t or -1
+__device__ __forceinline__ float prim_hit(const DevPrim* __restrict__ prims, int slot, V3 o, V3 d) {
+  const float4* p = reinterpret_cast<const float4*>(prims + slot);
+  float4 A = p[0], B = p[1], C = p[2];
+  int type = __float_as_int(C.y);
+  float dist = -1.0f;
+  if (type == 2) dist = tri_hit(o, d, mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), mk(B.z, B.w, C.x));
+  else if (type == 0) dist = sphere_hit(mk(A.x, A.y, A.z), A.w, o, d);
+  if (dist < 10000.0f && dist > -0.0f) return dist;          // K:449
+  return -1.0f;
+}
+
+struct Hit { float t; int slot; };
+
+struct Ctr { unsigned rays, V, L, S, T, samples; };
+
+// hit() K:468-512, the reference's order: a node that is entered continues with node + 1
+// (pre-order numbering), a node that is skipped, and every leaf, continues with its miss link.
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_threaded(const DevNode* __restrict__ nodes, const DevPrim* __restrict__ prims,
+                                                    V3 o, V3 d, Ctr& c) {
+  Hit best; best.t = 10000000.0f; best.slot = -1;
+  V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int node = 0;
+  if (COUNT) c.rays++;
+  while (node >= 0) {
+    const float4* np = reinterpret_cast<const float4*>(nodes + node);
+    float4 A = np[0], B = np[1];
+    float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
+    int prim = __float_as_int(A.w), miss = __float_as_int(B.w);
+    float dist;
+    if (COUNT) c.V++;
+    bool h = slab(o, inv, mn, mx, dist);
+    if (h && dist < best.t) {
+      if (prim >= 0) {
+        if (COUNT) c.L++;
+        float t = prim_hit(prims, prim, o, d);
+        if (t > -0.01f && t < best.t) { best.t = t; best.slot = prim; }   // K:488 (t is -1 or > 0)
+        node = miss;
+      } else {
+        node = node + 1;
+      }
+    } else {
+      node = miss;
+    }
+  }
+  if (best.slot < 0) best.t = -1.0f;
+  return best;
+}
+
+// hit() K:468-512 with the children visited near-first instead of child-0-first.
+//
+// What the reference returns is the primitive with the smallest t among all leaves whose
+// boxes (and ancestors' boxes) the ray enters, and, among equal t, the one its child-0-first
+// walk reaches first -- which is the one with the lowest leaf rank = slot (device_layout.h).
+// So any visiting order gives the same answer as long as (1) a subtree is skipped only when
+// its box is missed or entered no nearer than the best t so far (the reference's own pruning
+// test, K:484) and (2) ties on t go to the lower slot.  One 64-byte record holds both child
+// boxes; the far child waits on a per-lane stack in LDS (one dword per level, lane-major, so
+// a wave's pushes and pops never bank-conflict).  The tree is a median split, so its depth is
+// ceil(log2 N) <= 24 for N <= 2^24 (the host refuses deeper trees for this mode).
+constexpr int ORDERED_STACK = 24;
+
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_ordered(const DevPair* __restrict__ pairs, const DevPrim* __restrict__ prims,
+                                                   V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [level * 64] */) {
+  Hit best; best.t = 10000000.0f; best.slot = 0x7fffffff;
+  V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  int sp = 0;
+  int cur = 0;
+  if (COUNT) c.rays++;
+  for (;;) {
+    const float4* pp = reinterpret_cast<const float4*>(pairs + cur);
+    float4 A = pp[0], B = pp[1], C = pp[2], D = pp[3];
+    int c0 = __float_as_int(A.w), c1 = __float_as_int(B.w);
+    float mn0[3] = {A.x, A.y, A.z}, mx0[3] = {B.x, B.y, B.z};
+    float mn1[3] = {C.x, C.y, C.z}, mx1[3] = {D.x, D.y, D.z};
+    float d0, d1;
+    if (COUNT) c.V += 2;
+    bool h0 = slab(o, inv, mn0, mx0, d0) && d0 < best.t;
+    bool h1 = slab(o, inv, mn1, mx1, d1) && d1 < best.t;
+    if (h0 && c0 < 0) {
+      int slot = ~c0;
+      if (COUNT) c.L++;
+      float t = prim_hit(prims, slot, o, d);
+      if (t > 0.0f && (t < best.t || (t == best.t && slot < best.slot))) { best.t = t; best.slot = slot; }
+      h0 = false;
+    }
+    if (h1 && c1 < 0) {
+      if (d1 < best.t) {
+        int slot = ~c1;
+        if (COUNT) c.L++;
+        float t = prim_hit(prims, slot, o, d);
+        if (t > 0.0f && (t < best.t || (t == best.t && slot < best.slot))) { best.t = t; best.slot = slot; }
+      }
+      h1 = false;
+    }
+    h0 = h0 && d0 < best.t;
+    h1 = h1 && d1 < best.t;
+    if (h0 && h1) {
+      bool first0 = d0 <= d1;
+      int far_c = first0 ? c1 : c0;
+      cur = first0 ? c0 : c1;
+      if (sp < ORDERED_STACK) { stack[sp * 64] = far_c; sp++; }
+    } else if (h0) {
+      cur = c0;
+    } else if (h1) {
+      cur = c1;
+    } else {
+      if (sp == 0) break;
+      sp--;
+      cur = stack[sp * 64];
+    }
+  }
+  if (best.slot == 0x7fffffff) { best.t = -1.0f; best.slot = -1; }
+  return best;
+}
+
+// ------------------------------------------------------------------ shading helpers
+__device__ __forceinline__ V3 reflect(V3 v, V3 n) {              // K:667 (2.0*dot narrows exactly)
+  float k = 2.0f * dot(v, n);
+  return v - splat(k) * n;
+}
+__device__ __forceinline__ V3 refract(V3 uv, V3 n, float eta) {  // K:678-683
+  float cos_theta = (float)fmin((double)dot(uv * splat(-1.0f), n), 1.0);
+  V3 perp = splat(eta) * (uv + splat(cos_theta) * n);
+  float lp = length(perp);
+  float par = (float)(-__builtin_sqrt(__builtin_fabs(1.0 - (double)(lp * lp))));
+  return perp + splat(par) * n;
+}
+__device__ __forceinline__ float reflectance(float cosine, float ref_idx) {   // K:686-691
+  float r0 = (1 - ref_idx) / (1 + ref_idx);
+  r0 = r0 * r0;
+  float a = 1 - cosine;
+  float r = a;             // pow(float, int 5): CUDA powif = square and multiply in float
+  a = a * a;
+  a = a * a;
+  r = r * a;
+  return r0 + (1 - r0) * r;
+}
+
+// tex2D<uchar4>, point / wrap / normalised (K:830,841,962; descriptor K:1959-1964)
+template <bool COUNT>
+__device__ __forceinline__ uint32_t tex_fetch(const DevTex* __restrict__ tex, const uint32_t* __restrict__ texels, int id,
+                                              float u, float v, Ctr& c) {
+  DevTex t = tex[id];
+  if (COUNT) c.T++;
+  float fu = u - __builtin_floorf(u), fv = v - __builtin_floorf(v);
+  int i = f2i(__builtin_floorf(fu * (float)t.w)), j = f2i(__builtin_floorf(fv * (float)t.h));
+  if (i > t.w - 1) i = t.w - 1;
+  if (j > t.h - 1) j = t.h - 1;
+  if (i < 0) i = 0;
+  if (j < 0) j = 0;
+  return texels[(size_t)t.offset + (size_t)j * (size_t)t.w + (size_t)i];
+}
+__device__ __forceinline__ V3 rgb_of(uint32_t px) {
+  return mk(float(px & 255u) / 255, float((px >> 8) & 255u) / 255, float((px >> 16) & 255u) / 255);
+}
+
+// One path: raycolor K:787-982.  CLOSEST is the traversal functor.
+template <bool COUNT, class Closest>
+__device__ __forceinline__ V3 trace_path(const RenderParams& P, const Closest& closest, V3 origin, V3 dir, Xorwow& rng, Ctr& c) {
+  V3 raydir = dir, rayo = origin, atten = splat(1.0f);
+  for (int i = 0; i < P.max_depth; i++) {
+    Hit h = closest(rayo, raydir, c);
+    float t = h.t;
+    if (t > 0.0f) {
+      if (COUNT) c.S++;
+      V3 hitpoint = rayo + splat(t) * raydir;
+      // ---- getnormal K:703-773
+      const float4* pp = reinterpret_cast<const float4*>(P.prims + h.slot);
+      const float4* sp = reinterpret_cast<const float4*>(P.shade + h.slot);
+      float4 pA = pp[0], pB = pp[1], pC = pp[2];
+      float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
+      int type = __float_as_int(pC.y);
+      V3 texco = mk(0, 0, 0);
+      V3 N;
+      if (type == 0) {
+        N = (hitpoint - mk(pA.x, pA.y, pA.z)) / splat(pA.w);
+      } else if (type == 2) {
+        V3 v0 = mk(pA.x, pA.y, pA.z), v0v1 = mk(pA.w, pB.x, pB.y), v0v2 = mk(pB.z, pB.w, pC.x);
+        N = cross(v0v1, v0v2);
+        V3 pvec = cross(raydir, v0v2);
+        float det = dot(v0v1, pvec);
+        float invDet = 1 / det;
+        V3 tvec = rayo - v0;
+        float ux = dot(tvec, pvec) * invDet;
+        V3 qvec = cross(tvec, v0v1);
+        float uy = dot(raydir, qvec) * invDet;
+        float uz = 1 - ux - uy;
+        // texco = uz*t1 + ux*t2 + uy*t3 (the z components of t1..t3 are never read again)
+        texco.x = uz * s3.x + ux * s3.z + uy * s4.x;
+        texco.y = uz * s3.y + ux * s3.w + uy * s4.y;
+        V3 fn = mk(s0.x, s0.y, s0.z);
+        if (fn.z != -20) {
+          N = fn;
+          int flags = __float_as_int(s6.z);
+          if (s1.y != -20 && (flags & 1)) {     // n1.z
+            V3 n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x), n3 = mk(s2.y, s2.z, s2.w);
+            N = splat(uz) * n1 + splat(ux) * n2 + splat(uy) * n3;
+          }
+        }
+        N = normalized(N);
+      } else {
+        N = normalized(hitpoint - mk(pA.x, pA.y, pA.z));
+      }
+      bool front = dot(raydir, N) < 0;
+      N = front ? N : N * splat(-1.0f);
+      // ---- material inputs K:826-844
+      V3 col = mk(s4.z, s4.w, s5.x);
+      float add_x = s5.y, rough = s5.z;
+      int mat = __float_as_int(s5.w), texnum = __float_as_int(s6.x), rtexnum = __float_as_int(s6.y);
+      int flags = __float_as_int(s6.z);
+      V3 ocolor = col;
+      if (texnum >= 0) {
+        ocolor = rgb_of(tex_fetch<COUNT>(P.tex, P.texels, texnum, texco.x, -texco.y + 1, c));
+      } else if (flags & 2) {                     // checker K:776-784
+        float u2 = __builtin_floorf(texco.x * 10), v2 = __builtin_floorf(texco.y * 10);
+        float yes = u2 + v2;
+        ocolor = (__builtin_fmodf(yes, 2.0f) == 0) ? splat(0.8f) : col;
+      }
+      if (rtexnum >= 0) {
+        uint32_t px = tex_fetch<COUNT>(P.tex, P.texels, rtexnum, texco.x, -texco.y + 1, c);
+        rough = float(px & 255u) / 255 / 2;
+      }
+      // ---- scatter K:848-944
+      if (mat == 0) {
+        V3 target = hitpoint + N;
+        if (add_x == 0) target = target + rand_in_unit_sphere(rng);
+        else target = target + normalized(rand_in_unit_sphere(rng));
+        atten = atten * ocolor;
+        rayo = hitpoint;
+        raydir = normalized(target - hitpoint);
+      } else if (mat == 2) {
+        atten = atten * ocolor;
+        rayo = hitpoint;
+        raydir = reflect(normalized(raydir), N);
+      } else if (mat == 3) {
+        V3 refl = reflect(normalized(raydir), N);
+        atten = atten * ocolor;
+        rayo = hitpoint;
+        raydir = refl + splat(rough) * rand_in_unit_sphere(rng);
+      } else if (mat == 5) {
+        float r = randy(rng);
+        if (r > 0.8) {                           // float compared with the double 0.8
+          V3 refl = reflect(normalized(raydir), N);
+          atten = atten * ocolor;
+          rayo = hitpoint;
+          raydir = refl + splat(rough) * rand_in_unit_sphere(rng);
+        } else {
+          V3 target = hitpoint + N;
+          target = target + rand_in_unit_sphere(rng);
+          atten = atten * ocolor;
+          rayo = hitpoint;
+          raydir = normalized(target - hitpoint);
+        }
+      } else if (mat == 4) {
+        float ir = s5.z;                         // b[g].addional.y itself, not the textured roughness (K:917)
+        float ratio = front ? (1.0f / ir) : ir;
+        float cos_theta = (float)fmin((double)dot(normalized(raydir) * splat(-1.0f), N), 1.0);
+        float sin_theta = (float)__builtin_sqrt(1.0 - (double)(cos_theta * cos_theta));
+        bool cannot = (ratio * sin_theta) > 1.0f;
+        V3 out;
+        if (cannot || reflectance(cos_theta, ratio) > randy(rng)) out = reflect(normalized(raydir), N);
+        else out = refract(normalized(raydir), N, ratio);
+        atten = atten * ocolor;
+        rayo = hitpoint;
+        raydir = out;
+      } else {
+        return ocolor * atten;
+      }
+    } else {
+      V3 u = normalized(raydir);
+      if (P.backtex > -1) {                       // K:953-966
+        double ux = (double)u.x, uy = (double)u.y, uz = (double)u.z + 1.;
+        float m = (float)(2. * __builtin_sqrt(ux * ux + uy * uy + uz * uz));
+        V3 tt = u / splat(m) + splat(.5f);
+        tt.y = -tt.y;
+        V3 colr = rgb_of(tex_fetch<COUNT>(P.tex, P.texels, P.backtex, tt.x, -tt.y + 1, c));
+        return atten * colr * splat(P.bgint);
+      }
+      float t2 = (float)(0.5 * ((double)u.y + 1.0));   // K:971-974
+      float omt = (float)(1.0 - (double)t2);
+      V3 sky = splat(omt) * mk(1.0f, 1.0f, 1.0f) + splat(t2) * mk(0.5f, 0.7f, 1.0f);
+      return atten * sky * splat(P.bgint);
+    }
+  }
+  return mk(0, 0, 0);
+}
+
+// Kernel K:998-1093 for one pixel (the camera basis comes precomputed in P).
+template <bool COUNT, class Closest>
+__device__ __forceinline__ void render_pixel(const RenderParams& P, const Closest& closest, int x, int y, Ctr& c) {
+  V3 from = ld3(P.from), llc = ld3(P.llc), hor = ld3(P.hor), ver = ld3(P.ver), uu = ld3(P.uu), vu = ld3(P.vu);
+  V3 color = mk(0, 0, 0);
+  for (int s = 0; (float)s < P.spp_f; ++s) {
+    Xorwow rng;
+    rng.init(P.seed + (uint64_t)s * 0x9E3779B97F4A7C15ull + (uint64_t)((uint32_t)x + (uint32_t)y * P.seed_stride));
+    if (COUNT) c.samples++;
+    float nu = (float)(((double)(float)x + rng.uniform_double()) / P.den_w);
+    float nv = (float)(((double)(float)y + rng.uniform_double()) / P.den_h);
+    V3 rd = splat(P.lens_radius) * rand_in_unit_disk(rng);
+    V3 offset = uu * splat(rd.x) + vu * splat(rd.y);
+    V3 dir = llc + splat(nu) * hor + splat(nv) * ver - from - offset;
+    color = color + trace_path<COUNT>(P, closest, from + offset, dir, rng, c);
+  }
+  int r = f2i(color.x * 255 * P.scale), g = f2i(color.y * 255 * P.scale), b = f2i(color.z * 255 * P.scale);
+  int32_t* px = P.out + ((size_t)x * (size_t)P.H + (size_t)y) * 3;
+  if (P.accumulate) { px[0] += r; px[1] += g; px[2] += b; }
+  else { px[0] = r; px[1] = g; px[2] = b; }
+}
+
+}  // namespace dr

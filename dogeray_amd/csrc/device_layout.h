@@ -1,0 +1,108 @@
+// Device-resident scene layout (HBM), shared by the host lineariser and the HIP kernels.
+//
+// The reference uploads its host structs as they are: `bvh` (56 B, fields used by the kernel
+// at offsets 16..52) and `singleobject` (164 B, the three vertices at offsets 4, 16 and 120),
+// every frame (kernel.cu K:2618-2629).  Here the scene is uploaded once, renumbered and split
+// by access frequency:
+//
+//   nodes   32 B   {min.xyz, prim} {max.xyz, miss}      one record per node, DFS pre-order,
+//                                                        so "hit link" is always node + 1 and a
+//                                                        subtree is one contiguous range
+//   pairs   64 B   both children of an internal node     (ordered traversal: one fetch per step)
+//   prims   48 B   {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, type, -, -}   hot intersection data,
+//                                                        in leaf (DFS) order: slot = leaf rank
+//   shade  128 B   normals, uvs, material                cold, read once per shaded hit
+//   texels  4 B    RGBA8, all textures back to back + {offset, w, h} table
+//
+// Renumbering changes no result: node numbers never leave the BVH, and the slot order is the
+// order in which the reference's traversal reaches the leaves, which is what breaks ties.
+#pragma once
+#include <stdint.h>
+
+namespace dr {
+
+struct DevNode {       // 32 B, 32-B aligned
+  float mn[3];
+  int32_t prim;        // >= 0: leaf, slot of its primitive; -1: internal
+  float mx[3];
+  int32_t miss;        // node to continue with when this subtree is skipped / finished; -1 = end
+};
+
+// Ordered traversal: record k describes the two children of internal node k (pre-order index
+// of the internal node among ALL nodes is kept in `DevNode`; pairs are indexed by node id).
+struct DevPair {       // 64 B, 64-B aligned
+  float mn0[3];
+  int32_t c0;          // child 0: >= 0 internal node id, < 0: leaf, slot = ~c0
+  float mx0[3];
+  int32_t c1;          // child 1, same encoding
+  float mn1[3];
+  int32_t pad0;
+  float mx1[3];
+  int32_t pad1;
+};
+
+struct DevPrim {       // 48 B, 16-B aligned
+  float v0[3];         // triangle: vertex 0; sphere: centre
+  float e1x;           // triangle: e1.x;     sphere: radius
+  float e1y, e1z, e2x, e2y;
+  float e2z;
+  int32_t type;        // 0 sphere, 2 triangle, anything else: never hit
+  int32_t pad[2];
+};
+
+struct DevShade {      // 128 B
+  float norm[3];
+  float n1[3], n2[3], n3[3];
+  float t1[2], t2[2], t3[2];
+  float col[3];
+  float add_x, add_y;  // addional.x (diffuse mode), addional.y (roughness / IOR)
+  int32_t mat;
+  int32_t texnum, rtexnum;
+  int32_t flags;       // bit 0 smooth, bit 1 tex (checker)
+  int32_t type;
+  int32_t orig;        // index of the object in the .rts file
+  int32_t pad[3];
+};
+
+struct DevTex {
+  uint32_t offset;     // first texel in the texel array
+  int32_t w, h;
+  int32_t pad;
+};
+
+static_assert(sizeof(DevNode) == 32, "DevNode");
+static_assert(sizeof(DevPair) == 64, "DevPair");
+static_assert(sizeof(DevPrim) == 48, "DevPrim");
+static_assert(sizeof(DevShade) == 128, "DevShade");
+static_assert(sizeof(DevTex) == 16, "DevTex");
+
+// Everything one launch needs.  The camera basis (kernel.cu K:1016-1052) does not depend on
+// the pixel, so it is computed once on the host with the reference's arithmetic.
+struct RenderParams {
+  const DevNode* nodes;
+  const DevPair* pairs;
+  const DevPrim* prims;
+  const DevShade* shade;
+  const DevTex* tex;
+  const uint32_t* texels;
+  int32_t* out;                   // int32[W*H*3], pixel (x, y) at (x*H + y)*3
+  unsigned long long* counters;   // 6 words or null: rays, V, L, S, T, samples
+  float from[3], llc[3], hor[3], ver[3], uu[3], vu[3];
+  float lens_radius;
+  float bgint;
+  float scale;                    // (float)(1.0 / spp)
+  float spp_f;                    // settings[10]
+  double den_w, den_h;            // (double)float(W / divisor), (double)float(H / divisor)
+  uint64_t seed;
+  int32_t W, H;
+  int32_t gx, gy;                 // block grid of the reference launch (K:2636)
+  int32_t ncols;                  // block columns this context renders
+  int32_t stripe_mod, stripe_rem;
+  uint32_t seed_stride;           // blockDim.x * gridDim.x = 8 * gx (K:1065)
+  int32_t max_depth;
+  int32_t backtex;
+  int32_t accumulate;             // 0: store, 1: add into out
+  int32_t root_is_leaf;           // never (N >= 2), kept for clarity
+};
+
+}  // namespace dr

@@ -1,0 +1,184 @@
+/*
+ * dogeray_amd.h -- C ABI of the MI355X-native DOGERAY render path (libdogeray_amd.so).
+ *
+ * The reference (PhilipPragerUrbina/DOGERAY, raygpu/kernel.cu, cited as K:<line>) has no
+ * plugin/FFI layer.  The seam this library sits behind is the free function
+ *
+ *     cudaError_t CudaStarter(int3* outputr, bvh* nbvhtree, singleobject* allobjects,
+ *                             cudaTextureObject_t* texarray, int divisor);     K:138, K:2562-2669
+ *
+ * plus the host functions that feed it (getnum/read K:1113-1530, getppm* and readtextures
+ * K:1915-2018, build_bvh K:1864-1909) and the ~14 globals it reads implicitly
+ * (K:29-30,109,119-132).  Everything implicit there is an explicit argument here.
+ *
+ * Conventions
+ *   - plain C types only; every function returns DR_OK (0) or a negative dr_status;
+ *     dr_last_error() returns the message of the calling thread's last failure.
+ *   - a dr_scene lives on the host; a dr_context owns one GPU and the resident scene.
+ *   - one host thread per context at a time; calls are synchronous unless they say otherwise.
+ *   - there is NO CPU fallback: device entry points fail with DR_ERR_DEVICE without a GPU.
+ */
+#ifndef DOGERAY_AMD_H
+#define DOGERAY_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DR_ABI_VERSION 1
+
+typedef enum dr_status {
+  DR_OK = 0,
+  DR_ERR_INVALID = -1, /* bad argument / call order                                   */
+  DR_ERR_IO = -2,      /* file cannot be opened (reference: message box, K:1162,1524) */
+  DR_ERR_PARSE = -3,   /* stof/stoi would have thrown in the reference                */
+  DR_ERR_SCENE = -4,   /* scene the reference cannot build (fewer than 2 objects)     */
+  DR_ERR_DEVICE = -5,  /* HIP error, or no GPU                                        */
+  DR_ERR_NOMEM = -6
+} dr_status;
+
+typedef struct dr_scene dr_scene;     /* host: parsed .rts + textures + BVH */
+typedef struct dr_context dr_context; /* device: one GPU, one resident scene */
+
+const char* dr_last_error(void);
+int dr_abi_version(void);
+
+/* ------------------------------------------------------------------ host-side types ---- */
+
+/* struct singleobject (K:48-74), field for field; bools widened to int32. */
+typedef struct dr_object {
+  int32_t type;      /* 0 sphere, 2 triangle (K:440-447) */
+  float pos[3];      /* vertex 0 / sphere centre */
+  float rot[3];      /* vertex 2 */
+  float norm[3];     /* face normal, z == -20 means absent (K:55,750) */
+  float n1[3], n2[3], n3[3];
+  float t1[3], t2[3], t3[3];
+  int32_t smooth, tex, mat;
+  float dim[3];      /* vertex 1, or radius in dim[0] */
+  float col[3];
+  int32_t texnum, rtexnum;
+  float addional[3]; /* [1] = roughness / IOR, [0] = diffuse mode (K:827,852,917) */
+} dr_object;
+
+/* struct bvh (K:79-96), field for field. */
+typedef struct dr_bvh_node {
+  int32_t active;
+  int32_t children[2];
+  int32_t count;
+  int32_t hit_node, miss_node;
+  int32_t under;
+  float min[3], max[3];
+  int32_t end;
+} dr_bvh_node;
+
+/* The globals the '*' settings line fills (K:1223-1299; defaults K:29-30,109,123-132). */
+typedef struct dr_settings {
+  float campos[3], look[3];
+  float aperture, focus_dist;
+  int32_t fov, max_depth, spp;
+  float background;
+  int32_t backtex;
+  int32_t width, height;
+} dr_settings;
+
+/* ------------------------------------------------------------------ scene ingest -------- */
+
+/* getnum + getppmnum/getppmpaths + read + readtextures' file loading (K:2055-2082).
+ * texture_dir: directory scanned for entries whose path contains "ppm"/"PPM" (the reference
+ * scans the process cwd, K:1981); NULL = current directory, "" = no textures.  Entries are
+ * taken in sorted name order. */
+int dr_scene_load(const char* rts_path, const char* texture_dir, dr_scene** out);
+void dr_scene_free(dr_scene* s);
+
+int dr_scene_num_objects(const dr_scene* s);            /* N = object lines (objnum - 1)   */
+int dr_scene_get_objects(const dr_scene* s, dr_object* out /* N + 1 entries */);
+int dr_scene_get_settings(const dr_scene* s, dr_settings* out);
+int dr_scene_set_settings(dr_scene* s, const dr_settings* in);
+int dr_scene_num_textures(const dr_scene* s);
+int dr_scene_texture_info(const dr_scene* s, int i, int* width, int* height);
+int dr_scene_texture_data(const dr_scene* s, int i, uint8_t* rgba /* w*h*4 */);
+
+/* build_bvh (K:1864-1909): same tree, same node numbering, same float bounds.
+ * nthreads <= 0: use all hardware threads. */
+int dr_scene_build_bvh(dr_scene* s, int nthreads);
+int dr_scene_bvh_size(const dr_scene* s);                /* bvhnum = 2 * (N + 1), K:2073   */
+int dr_scene_bvh_used(const dr_scene* s);                /* actualbvhnum = 2N - 1          */
+int dr_scene_get_bvh(const dr_scene* s, dr_bvh_node* out /* dr_scene_bvh_size entries */);
+
+/* ------------------------------------------------------------------ device -------------- */
+
+int dr_device_count(void);
+int dr_context_create(int device_ordinal, dr_context** out);
+void dr_context_destroy(dr_context* c);
+
+/* Uploads nodes, primitives, shading records and textures ONCE (the reference re-uploads all
+ * of them on every CudaStarter call, K:2604-2629).  The BVH must have been built. */
+int dr_context_upload_scene(dr_context* c, const dr_scene* s);
+
+/* Framebuffer partition for multi-GPU: this context renders only the 8-pixel-wide block
+ * columns bx with bx % mod == rem; other pixels stay 0.  Default (1, 0) = everything. */
+int dr_context_set_stripe(dr_context* c, int mod, int rem);
+
+/* Traversal used by the megakernel.  Both return the same closest hit as hit() K:468-512.
+ *   DR_TRAVERSAL_THREADED  the reference's order: hit/miss links, child 0 first
+ *   DR_TRAVERSAL_ORDERED   near child first with a short per-lane stack, ties resolved to the
+ *                          leaf the reference order would have reached first            */
+enum { DR_TRAVERSAL_THREADED = 0, DR_TRAVERSAL_ORDERED = 1 };
+int dr_context_set_traversal(dr_context* c, int mode);
+
+/* One CudaStarter call.  settings13 = { cam.xyz, look.xyz, aperture, focus, fov, max_depth,
+ * spp, divisor, backtex } exactly as packed at K:2581; W,H = SCREEN_WIDTH/HEIGHT;
+ * background = backgroundintensity[0] (K:108,2103); frame_seed replaces clock() at K:1065.
+ * out_int3 (host, may be NULL) receives int32[W*H*3], pixel (x,y) at (x*H + y)*3 (K:1006):
+ * trunc(mean colour * 255), unclamped; pixels outside the rendered sub-rectangle are 0. */
+int dr_render_frame(dr_context* c, const float settings13[13], int W, int H, float background,
+                    uint64_t frame_seed, int32_t* out_int3);
+
+/* Progressive accumulation kept on the device (the reference accumulates on the CPU,
+ * K:2213-2218).  dr_accum_reset zeroes the W*H*3 int32 accumulator; dr_render_accumulate
+ * renders `nframes` frames with seeds frame_seed + k*seed_stride and adds each into it
+ * (no host synchronisation between frames; returns after the last one has finished). */
+int dr_accum_reset(dr_context* c, int W, int H);
+int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H, float background,
+                         uint64_t frame_seed, uint64_t seed_stride, int nframes);
+int dr_accum_read(dr_context* c, int32_t* out_int3 /* W*H*3 */);
+/* The display divide of K:2287: rgb8[(y*W + x)*3 + ch] = clamp(acc / divide_by, 0, 255). */
+int dr_accum_present(dr_context* c, int divide_by, uint8_t* out_rgb8 /* W*H*3, row-major */);
+/* Device address of the accumulator (int32[W*H*3]) for device-side gathers (RCCL). */
+int dr_accum_device_ptr(dr_context* c, void** dev_ptr, uint64_t* bytes);
+
+/* Counters and timings since the last dr_stats_reset.  Ray = one hit() call (K:800). */
+typedef struct dr_stats {
+  uint64_t frames;        /* kernel launches                                            */
+  uint64_t samples;       /* primary samples                                            */
+  uint64_t rays;          /* closest-hit queries (counted only when counters are on)    */
+  uint64_t node_visits;   /* V: AABB tests performed by the kernel's traversal          */
+  uint64_t prim_tests;    /* L                                                          */
+  uint64_t shades;        /* S: hits shaded                                             */
+  uint64_t texels;        /* T                                                          */
+  double kernel_ms;       /* sum of HIP-event durations of the render kernel launches   */
+} dr_stats;
+int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the kernel; off by default */
+int dr_stats_reset(dr_context* c);
+int dr_stats_get(dr_context* c, dr_stats* out);
+
+/* ------------------------------------------------------------------ known-answer hooks -- */
+/* Run single device functions on caller data (host pointers), for parity tests. */
+int dr_kat_rng(dr_context* c, uint64_t seed, int n, double* out);
+int dr_kat_aabb(dr_context* c, int n, const float* o, const float* d, const float* mn, const float* mx,
+                int32_t* hit, float* dist);
+int dr_kat_tri(dr_context* c, int n, const float* o, const float* d, const float* v0, const float* v1,
+               const float* v2, float* t);
+int dr_kat_sphere(dr_context* c, int n, const float* o, const float* d, const float* centre,
+                  const float* radius, float* t);
+int dr_kat_optics(dr_context* c, int n, const float* v, const float* nrm, const float* eta, float* refl,
+                  float* refr, float* schlick);
+/* closest hit against the resident scene: t (-1 = miss) and ORIGINAL object index */
+int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DOGERAY_AMD_H */

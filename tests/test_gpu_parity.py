@@ -1,0 +1,262 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bar: integer / index work bit-exact; the float pipeline is specified operation by operation
+(-ffp-contract=off on both sides, IEEE divide/sqrt, no libm transcendental on the device), so
+frames are expected to be IDENTICAL int32 triples.  north_star's tolerance is 1e-4 relative per
+channel; the asserts below are stricter (exact) and print the measured agreement.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import CUBE_SETTINGS, SCENES, frame_stats, with_settings
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dr():
+    import dogeray_amd
+    assert dogeray_amd.device_count() >= 1, "no GPU visible: the HIP path cannot run (there is no fallback)"
+    return dogeray_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import orc as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def ctx(dr):
+    c = dr.Context(0)
+    yield c
+    c.close()
+
+
+def rand_dirs(rng, n):
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[rng.random(n) < 0.05, 0] = 0.0          # axis-parallel rays: 1/0 = inf in the slab test
+    d[rng.random(n) < 0.02, 1] = -0.0
+    return d
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def test_rng_xorwow(ctx, orc):
+    for seed in (0, 1, 12345, 2 ** 32 + 7, 2 ** 64 - 1, 1 + 1000003 * 5 + 255 + 255 * 256):
+        g = ctx.kat_rng(seed, 257)
+        o = orc.kat_rng(seed, 257)
+        assert np.array_equal(g.view(np.uint64), o.view(np.uint64)), "seed %d" % seed
+        assert g.min() > 0.0 and g.max() < 1.0
+
+
+def test_aabb(ctx, orc):
+    rng = np.random.default_rng(1)
+    n = 200_000
+    o = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+    d = rand_dirs(rng, n)
+    c = rng.uniform(-5, 5, size=(n, 3)).astype(np.float32)
+    e = rng.uniform(0, 3, size=(n, 3)).astype(np.float32)
+    mn, mx = c - e, c + e
+    o[:1000] = mn[:1000]                       # origin on a box face: (min - o) = 0, times inf = NaN
+    gh, gd = ctx.kat_aabb(o, d, mn, mx)
+    oh, od = orc.kat_aabb(o, d, mn, mx)
+    assert np.array_equal(gh, oh)
+    assert np.array_equal(bits(gd), bits(od))
+    assert 0.05 < gh.mean() < 0.95
+
+
+def test_triangle(ctx, orc):
+    rng = np.random.default_rng(2)
+    n = 200_000
+    v0 = rng.uniform(-2, 2, size=(n, 3)).astype(np.float32)
+    v1 = (v0 + rng.uniform(-1, 1, size=(n, 3))).astype(np.float32)
+    v2 = (v0 + rng.uniform(-1, 1, size=(n, 3))).astype(np.float32)
+    o = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+    target = (v0 + v1 + v2) / 3 + rng.normal(scale=0.4, size=(n, 3))
+    d = (target - o).astype(np.float32)
+    d[:2000] = (v1[:2000] - v0[:2000])         # rays in the triangle's plane: |a| < EPSILON branch
+    g = ctx.kat_tri(o, d, v0, v1, v2)
+    r = orc.kat_tri(o, d, v0, v1, v2)
+    assert np.array_equal(bits(g), bits(r))
+    assert 0.1 < (g > 0).mean() < 0.9
+
+
+def test_sphere(ctx, orc):
+    rng = np.random.default_rng(3)
+    n = 100_000
+    c = rng.uniform(-2, 2, size=(n, 3)).astype(np.float32)
+    r = rng.uniform(0.1, 1.5, size=n).astype(np.float32)
+    o = rng.uniform(-4, 4, size=(n, 3)).astype(np.float32)
+    d = (c + rng.normal(scale=0.7, size=(n, 3)) - o).astype(np.float32)
+    g = ctx.kat_sphere(o, d, c, r)
+    ref = orc.kat_sphere(o, d, c, r)
+    assert np.array_equal(bits(g), bits(ref))
+    assert 0.1 < (g > 0).mean() < 0.95
+
+
+def test_optics(ctx, orc):
+    rng = np.random.default_rng(4)
+    n = 100_000
+    v = rng.normal(size=(n, 3)).astype(np.float32)
+    v /= np.linalg.norm(v, axis=1, keepdims=True).astype(np.float32)
+    nr = rng.normal(size=(n, 3)).astype(np.float32)
+    nr /= np.linalg.norm(nr, axis=1, keepdims=True).astype(np.float32)
+    eta = rng.choice(np.array([1.5, 1 / 1.5, 1.33, 2.4, 1.0], dtype=np.float32), size=n)
+    g = ctx.kat_optics(v, nr, eta)
+    r = orc.kat_optics(v, nr, eta)
+    for a, b in zip(g, r):
+        assert np.array_equal(bits(a), bits(b))
+
+
+def _load_both(dr, orc, path, texdir=""):
+    ps = dr.Scene.load(path, texdir)
+    ps.build_bvh()
+    os_ = orc.Scene(path, texdir if texdir else None)
+    os_.build_bvh()
+    return ps, os_
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_closest_hit_queries(dr, orc, ctx, synth, mode):
+    """hit() K:468-512: t bit-exact and the same object index, for both traversals."""
+    rng = np.random.default_rng(5)
+    for path in (os.path.join(synth["dir"], "hf_small.rts"), os.path.join(synth["dir"], "city_small.rts"),
+                 os.path.join(SCENES, "scene.rts"), os.path.join(SCENES, "lots.rts")):
+        ps, os_ = _load_both(dr, orc, path)
+        ctx.upload(ps)
+        ctx.set_traversal(mode)
+        n = 100_000
+        o = rng.uniform(-12, 12, size=(n, 3)).astype(np.float32)
+        tgt = rng.uniform(-6, 6, size=(n, 3)).astype(np.float32)
+        d = (tgt - o).astype(np.float32)
+        gt, gi = ctx.kat_hit(o, d)
+        rt, ri = os_.kat_hit(o, d)
+        assert np.array_equal(bits(gt), bits(rt)), path
+        assert np.array_equal(gi, ri), path
+        assert (gt > 0).mean() > 0.02, path
+    ctx.set_traversal(0)
+
+
+def _render_pair(dr, orc, ctx, path, texdir, W, H, div, seed, spp=None, depth=None, mode=0):
+    ps, os_ = _load_both(dr, orc, path, texdir)
+    ctx.upload(ps)
+    ctx.set_traversal(mode)
+    s = ps.settings()
+    so = os_.settings()
+    assert bytes(s) == bytes(so)
+    st = dr.pack_settings13(s, div, spp=spp, depth=depth)
+    ctx.enable_counters(True)
+    ctx.stats_reset()
+    g = ctx.render_frame(st, W, H, s.background, seed)
+    stats = ctx.stats()
+    ctx.enable_counters(False)
+    g2 = ctx.render_frame(st, W, H, s.background, seed)     # the timed (non-counting) build of the kernel
+    assert np.array_equal(g, g2), "counting and non-counting kernels disagree"
+    r, rc = os_.render(st, W, H, s.background, seed, nthreads=4)
+    ctx.set_traversal(0)
+    return g, r, stats, rc
+
+
+def _assert_frames(g, r, what):
+    frac, maxdiff = frame_stats(g, r)
+    print("%s: %.6f of pixels identical, max |diff| = %d" % (what, frac, maxdiff))
+    assert frac == 1.0, "%s: only %.6f of pixels identical (max diff %d)" % (what, frac, maxdiff)
+
+
+def test_cube_ladder_frames(dr, orc, ctx, tmp_path):
+    """Config C1: samples/cube.rts 256x256 1 spp, every preview-ladder stage (K:2169-2211)."""
+    path = with_settings(os.path.join(SCENES, "cube.rts"), str(tmp_path / "cube256.rts"), CUBE_SETTINGS)
+    for k, (div, spp, depth) in enumerate([(8, None, None), (4, 1, 2), (2, 1, 2), (1, 1, 2), (1, None, None), (1, None, None)]):
+        seed = 1 + 1000003 * k
+        g, r, stats, rc = _render_pair(dr, orc, ctx, path, "", 256, 256, div, seed, spp, depth)
+        _assert_frames(g, r, "cube stage %d" % k)
+        assert g[256 // div:, :, :].max() == 0 and g[:, 256 // div:, :].max() == 0   # unrendered margin is 0
+        for a, b in (("rays", "rays"), ("node_visits", "V"), ("prim_tests", "L"), ("shades", "S"), ("texels", "T"), ("samples", "samples")):
+            assert stats[a] == rc[b], (k, a, stats[a], rc[b])
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_scene_frames(dr, orc, ctx, synth, mode):
+    """Spheres, every material, textures, checker, env map, smooth normals, large meshes."""
+    cases = [
+        (os.path.join(SCENES, "scene.rts"), "", 320, 192),              # spheres + the unsupported type 1
+        (os.path.join(synth["dir"], "matball.rts"), synth["tex"], 256, 256),
+        (os.path.join(SCENES, "glass.rts"), "", 320, 192),
+        (os.path.join(SCENES, "cow.rts"), synth["tex"], 320, 192),      # a.ppm + testtwo.ppm by name
+        (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192),   # env map + roughness texture
+        (os.path.join(synth["dir"], "hf_small.rts"), "", 320, 192),
+        (os.path.join(synth["dir"], "bunny_small.rts"), "", 320, 192),
+        (os.path.join(synth["dir"], "city_small.rts"), "", 320, 192),
+    ]
+    for path, tex, W, H in cases:
+        for seed in (3, 1 + 1000003 * 7):
+            g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, 1, seed, mode=mode)
+            _assert_frames(g, r, "%s seed %d mode %d" % (os.path.basename(path), seed, mode))
+            assert stats["rays"] == rc["rays"] and stats["shades"] == rc["S"] and stats["texels"] == rc["T"]
+            if mode == 0:
+                assert stats["node_visits"] == rc["V"] and stats["prim_tests"] == rc["L"]
+            else:
+                print("   node visits: ordered %d vs reference order %d" % (stats["node_visits"], rc["V"]))
+
+
+def test_spp_and_aperture(dr, orc, ctx, synth, tmp_path):
+    """spp > 1 inside one launch (per-sample reseed, K:1059-1065) and a wide lens (K:1071-1073)."""
+    src = os.path.join(synth["dir"], "matball.rts")
+    path = with_settings(src, str(tmp_path / "mb4.rts"),
+                         "*,0,-2.5,7,0.6,0,-0.5,0,7,50,6,4,0.9,synth_env.ppm,192,128")
+    g, r, stats, rc = _render_pair(dr, orc, ctx, path, synth["tex"], 192, 128, 1, 77)
+    _assert_frames(g, r, "matball 4 spp")
+    assert stats["samples"] == 192 * 128 * 4
+
+
+def test_progressive_accumulation(dr, orc, ctx, tmp_path):
+    """Present loop K:2154-2224: ladder, then accumulate; display = clamp(sum / (iter - pnum))."""
+    path = with_settings(os.path.join(SCENES, "cube.rts"), str(tmp_path / "cube256.rts"), CUBE_SETTINGS)
+    ps, os_ = _load_both(dr, orc, path)
+    ctx.upload(ps)
+    s = ps.settings()
+    pr = dr.ProgressiveRenderer(ctx, s, seed_base=1, seed_stride=1000003)
+    outr = None
+    for k in range(7):
+        td, divide_by = pr.step()
+        if k < 4:
+            div = (8, 4, 2, 1)[k]
+            st = dr.pack_settings13(s, div, spp=(None if k == 0 else 1), depth=(None if k == 0 else 2))
+            outr, _ = os_.render(st, 256, 256, s.background, 1 + 1000003 * k, nthreads=4)
+            assert td == div and divide_by == 1
+        else:
+            f, _ = os_.render(dr.pack_settings13(s, 1), 256, 256, s.background, 1 + 1000003 * k, nthreads=4)
+            outr = outr + f
+            assert td == 1 and divide_by == k - 2
+        acc = ctx.accum_read()
+        assert np.array_equal(acc, outr), "iteration %d" % k
+        img = pr.image(divide_by)
+        quot = (np.abs(outr) // divide_by) * np.sign(outr)          # C integer division truncates toward zero
+        want = np.clip(quot, 0, 255).astype(np.uint8)
+        assert np.array_equal(img, want.transpose(1, 0, 2))
+
+
+def test_stripes_partition_the_frame(dr, ctx, synth):
+    """Multi-GPU partition: block columns bx % R == r; the union over r is the 1-GPU frame."""
+    ps = dr.Scene.load(os.path.join(synth["dir"], "hf_small.rts"))
+    ps.build_bvh()
+    ctx.upload(ps)
+    s = ps.settings()
+    st = dr.pack_settings13(s, 1)
+    full = ctx.render_frame(st, 320, 192, s.background, 9)
+    total = np.zeros_like(full)
+    for R in (2, 3, 8):
+        total[:] = 0
+        for r in range(R):
+            ctx.set_stripe(R, r)
+            part = ctx.render_frame(st, 320, 192, s.background, 9)
+            cols = np.arange(320) // 8 % R == r
+            assert part[~cols].max() == 0 and part[~cols].min() == 0
+            total += part
+        assert np.array_equal(total, full), R
+    ctx.set_stripe(1, 0)
