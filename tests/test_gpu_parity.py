@@ -175,7 +175,8 @@ def test_cube_ladder_frames(dr, orc, ctx, tmp_path):
         seed = 1 + 1000003 * k
         g, r, stats, rc = _render_pair(dr, orc, ctx, path, "", 256, 256, div, seed, spp, depth)
         _assert_frames(g, r, "cube stage %d" % k)
-        assert g[256 // div:, :, :].max() == 0 and g[:, 256 // div:, :].max() == 0   # unrendered margin is 0
+        if div > 1:   # unrendered margin is 0
+            assert not g[256 // div:, :, :].any() and not g[:, 256 // div:, :].any()
         for a, b in (("rays", "rays"), ("node_visits", "V"), ("prim_tests", "L"), ("shades", "S"), ("texels", "T"), ("samples", "samples")):
             assert stats[a] == rc[b], (k, a, stats[a], rc[b])
 
