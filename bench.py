@@ -57,10 +57,10 @@ def main():
     ap.add_argument("--verts", type=int, default=709, help="heightfield vertices per side (709 -> 1 002 528 triangles)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--traversal", choices=["threaded", "ordered"], default="ordered")
+    ap.add_argument("--traversal", choices=["threaded", "ordered"], default="threaded")
     ap.add_argument("--gather-every", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-col-mod", type=int, default=4, help="cpu_baseline renders every n-th block column")
+    ap.add_argument("--cpu-col-mod", type=int, default=1, help="cpu_baseline renders every n-th block column")
     ap.add_argument("--cache", default=os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"))
     args = ap.parse_args()
 
@@ -218,6 +218,8 @@ def main():
             "note": "algorithmic bytes use the reference traversal's visit counts (SURVEY 8(d)); kernel_own_* uses this kernel's own counts",
         },
         "setup_s": {"parse": t_parse, "bvh_build": t_bvh, "upload": t_upload},
+        "simd_efficiency": {"node_loop": ref_order["node_visits"] / max(1, ref_order["trav_slots"]),
+                            "bounce_loop": ref_order["rays"] / max(1, ref_order["ray_slots"])},
     }
 
     if world == 1 and not args.no_cpu_baseline:

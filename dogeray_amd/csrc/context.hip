@@ -24,7 +24,7 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
   __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
-  Ctr c = {0, 0, 0, 0, 0, 0};
+  Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
   if (tile < P.ncols * P.gy) {
     const int col = tile / P.gy, by = tile - col * P.gy;
     const int bx = P.stripe_rem + col * P.stripe_mod;
@@ -39,8 +39,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
     }
   }
   if (COUNT) {
-    unsigned v[6] = {c.rays, c.V, c.L, c.S, c.T, c.samples};
-    for (int k = 0; k < 6; k++) {
+    unsigned v[8] = {c.rays, c.V, c.L, c.S, c.T, c.samples, c.trav_slots, c.ray_slots};
+    for (int k = 0; k < 8; k++) {
       unsigned long long s = v[k];
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
       if (lane == 0 && s) atomicAdd(&P.counters[k], s);
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, con
   __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : 1];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  Ctr c = {0, 0, 0, 0, 0, 0};
+  Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
   Hit h;
   if (MODE == DR_TRAVERSAL_ORDERED) {
     int* stack = lds_stack + (threadIdx.x >> 6) * (ORDERED_STACK * 64) + (threadIdx.x & 63);
@@ -295,8 +295,8 @@ int dr_context_create(int device_ordinal, dr_context** out) {
   c->device = device_ordinal;
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-      hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void**)&c->counters, 6 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(c->counters, 0, 6 * sizeof(unsigned long long)) != hipSuccess) {
+      hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void**)&c->counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
     set_error("cannot create stream/events");
     dr_context_destroy(c);
     return DR_ERR_DEVICE;
@@ -467,7 +467,7 @@ int dr_stats_reset(dr_context* c) {
   if (!c) { set_error("null context"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemset(c->counters, 0, 6 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)));
   memset(&c->stats, 0, sizeof(c->stats));
   return DR_OK;
 }
@@ -476,11 +476,12 @@ int dr_stats_get(dr_context* c, dr_stats* out) {
   if (!c || !out) { set_error("null argument"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  unsigned long long h[6];
+  unsigned long long h[8];
   HIP_TRY(hipMemcpy(h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
   *out = c->stats;
   out->rays = h[0]; out->node_visits = h[1]; out->prim_tests = h[2]; out->shades = h[3]; out->texels = h[4];
   if (c->count) out->samples = h[5];
+  out->trav_slots = h[6]; out->ray_slots = h[7];
   return DR_OK;
 }
 

@@ -168,7 +168,7 @@ __device__ __forceinline__ float prim_hit(const DevPrim* __restrict__ prims, int
 
 struct Hit { float t; int slot; };
 
-struct Ctr { unsigned rays, V, L, S, T, samples; };
+struct Ctr { unsigned rays, V, L, S, T, samples, trav_slots, ray_slots; };   // *_slots: 64 per wave-level iteration / query (SIMD efficiency probes)
 
 // hit() K:468-512, the reference's order: a node that is entered continues with node + 1
 // (pre-order numbering), a node that is skipped, and every leaf, continues with its miss link.
@@ -178,8 +178,9 @@ __device__ __forceinline__ Hit closest_hit_threaded(const DevNode* __restrict__ 
   Hit best; best.t = 10000000.0f; best.slot = -1;
   V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   int node = 0;
-  if (COUNT) c.rays++;
+  if (COUNT) { c.rays++; if (__lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u) c.ray_slots += 64; }
   while (node >= 0) {
+    if (COUNT) { if (__lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u) c.trav_slots += 64; }
     const float4* np = reinterpret_cast<const float4*>(nodes + node);
     float4 A = np[0], B = np[1];
     float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};

@@ -86,7 +86,7 @@ struct RenderParams {
   const DevTex* tex;
   const uint32_t* texels;
   int32_t* out;                   // int32[W*H*3], pixel (x, y) at (x*H + y)*3
-  unsigned long long* counters;   // 6 words or null: rays, V, L, S, T, samples
+  unsigned long long* counters;   // 8 words or null: rays, V, L, S, T, samples, trav_slots, ray_slots
   float from[3], llc[3], hor[3], ver[3], uu[3], vu[3];
   float lens_radius;
   float bgint;

@@ -159,6 +159,8 @@ typedef struct dr_stats {
   uint64_t shades;        /* S: hits shaded                                             */
   uint64_t texels;        /* T                                                          */
   double kernel_ms;       /* sum of HIP-event durations of the render kernel launches   */
+  uint64_t trav_slots;    /* 64 x wave-level traversal iterations: node_visits / trav_slots = SIMD efficiency of the node loop */
+  uint64_t ray_slots;     /* 64 x wave-level closest-hit calls:    rays / ray_slots = SIMD efficiency of the bounce loop       */
 } dr_stats;
 int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the kernel; off by default */
 int dr_stats_reset(dr_context* c);
