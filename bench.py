@@ -171,7 +171,9 @@ def main():
         return
 
     frames = args.steps
-    kernel_ms = timed["kernel_ms"] / max(1, timed["frames"])          # HIP events on the render stream, rank 0
+    kernel_ms = timed["kernel_ms"] / max(1, timed["frames"])          # HIP events on the render stream, rank 0; per FRAME
+    launch_ms = timed["kernel_ms"] / max(1, timed["launches"])        # per kernel launch (a launch may cover a batch of frames)
+    frames_per_launch = timed["frames"] / max(1, timed["launches"])
     abytes = algorithmic_bytes(ref_order, frames, W if world == 1 else W // world, H) / frames
     kbytes = algorithmic_bytes(own, frames, W if world == 1 else W // world, H) / frames
     achieved = abytes / (kernel_ms * 1e-3) / 1e9
@@ -212,12 +214,14 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "algorithmic_bytes_per_launch": abytes,
-            "kernel_own_visit_bytes_per_launch": kbytes,
-            "launch_ms": kernel_ms,
+            "algorithmic_bytes_per_launch": abytes * frames_per_launch,
+            "kernel_own_visit_bytes_per_launch": kbytes * frames_per_launch,
+            "launch_ms": launch_ms,
+            "frames_per_launch": frames_per_launch,
             "note": "algorithmic bytes use the reference traversal's visit counts (SURVEY 8(d)); kernel_own_* uses this kernel's own counts",
         },
         "setup_s": {"parse": t_parse, "bvh_build": t_bvh, "upload": t_upload},
+        "diag": own.get("diag"),
         "simd_efficiency": {"node_loop": ref_order["node_visits"] / max(1, ref_order["trav_slots"]),
                             "bounce_loop": ref_order["rays"] / max(1, ref_order["ray_slots"])},
     }

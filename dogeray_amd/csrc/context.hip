@@ -19,8 +19,8 @@ namespace dr {
 // tiles per 256-thread workgroup.  Tiles are numbered column-major over the block columns this
 // context owns, so neighbouring waves work on vertically adjacent tiles (coherent rays, and the
 // column-major framebuffer gives each wave eight 96-byte runs).
-template <bool COUNT, int MODE>
-__global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
+template <bool COUNT, int MODE, int OCC>
+__global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
   __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : 1];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
@@ -34,7 +34,8 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
       auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_ordered<COUNT>(P.pairs, P.prims, o, d, cc, stack); };
       render_pixel<COUNT>(P, closest, x, y, c);
     } else {
-      auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_threaded<COUNT>(P.nodes, P.prims, o, d, cc); };
+      const WalkRsrc walk = walk_rsrc(P);
+      auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_threaded<COUNT>(walk, o, d, cc); };
       render_pixel<COUNT>(P, closest, x, y, c);
     }
   }
@@ -45,6 +46,206 @@ __global__ __launch_bounds__(256) void render_kernel(RenderParams P) {
       for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
       if (lane == 0 && s) atomicAdd(&P.counters[k], s);
     }
+  }
+}
+
+// Persistent variant of the same megakernel.
+//
+// In the per-tile kernel above a wave's 64 lanes walk the BVH in lock step until the LAST of
+// them is done, then shade, then walk again: on the 1M-triangle bench scene only 36 % of the
+// lane-slots of the node loop and 77 % of the bounce loop do useful work.  Here a wave is a
+// pool of 64 path slots.  Every loop iteration advances each walking lane by one node; as soon
+// as fewer than TRAV_MIN lanes are still walking, the finished lanes are shaded (hit or miss),
+// scatter into their next ray, or -- when their path has ended -- store their pixel and take the
+// next unrendered pixel, so the node loop stays full until the frame runs out of pixels.
+// Pixels are handed out in 8x8 tiles from one global counter (first tile = wave id, then
+// atomicAdd), lane l of a tile is pixel (l >> 3, l & 7) of that tile: which lane renders a pixel
+// does not enter its arithmetic (the RNG seed is a function of x, y and the frame, K:1065), so
+// the frame is identical to the per-tile kernel's.
+//
+// lane states (kept in `tr.node`): >= 0 walking; -1 walk finished, needs shading; -2 needs a new
+// sample or pixel; -3 retired.
+template <bool COUNT, int OCC, int TRAV_MIN>
+__global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
+                                                                     const int* __restrict__ tile_order, unsigned* __restrict__ pixel_cost) {
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int ntiles = P.ncols * P.gy;
+  const int nwork = ntiles * P.batch;          // queue length: every tile of every frame of the batch
+  const WalkRsrc walk = walk_rsrc(P);
+  Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
+  // wave-uniform work cursor
+  // The queue hands out positions q = 0, 1, 2, ...; tile_order (when present) maps a position to
+  // a tile so that the tiles that were most expensive in the previous frame of this view start
+  // first (longest-processing-time-first: the kernel's duration is otherwise set by whichever
+  // expensive tile happens to start last).
+  // A launch may cover a batch of frames (same view, consecutive seeds): position q is tile
+  // order[q / batch] of frame q % batch, so the expensive tiles of ALL frames start first and the
+  // tail of one frame (its longest paths) overlaps the bulk of the others.
+  int cur_tile = ntiles, cur_frame = 0;        // chunk being handed out; ntiles = none
+  if (wave_id < nwork) { const int t = wave_id / P.batch; cur_frame = wave_id - t * P.batch; cur_tile = tile_order ? tile_order[t] : t; }
+  int cur_next = 0;                // next unassigned lane-in-tile of cur_tile (64 = exhausted)
+  // per-lane path slot
+  Trav tr; tr.node = -2; tr.best_t = 0; tr.best_slot = -1;
+  Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
+  V3 inv = mk(0, 0, 0), color = mk(0, 0, 0);
+  Xorwow rng; rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = rng.d = 0;
+  int px = -1, py = 0, sample = 0, bounce = 0;
+  int frame = 0;                   // frame of the batch the pixel in this slot belongs to
+  int pcode = 0;                   // tile * 64 + lane-in-tile of the pixel in this slot
+  unsigned steps = 0;              // node steps spent on the pixel in this slot (the cost fed back)
+  const bool degenerate = P.max_depth <= 0 || !(P.spp_f > 0.0f);
+
+  // diagnostic stamps (counting build only): wave lifetime, cycles inside the shade/refill phase
+  unsigned long long t_begin = 0, t_phase = 0, n_iter = 0, n_phase = 0;
+  if (COUNT) t_begin = __builtin_readcyclecounter();
+  for (;;) {
+    const unsigned long long walking = __ballot(tr.node >= 0);
+    if (COUNT) n_iter++;
+    if (__popcll(walking) < TRAV_MIN) {
+      unsigned long long t0 = 0;
+      if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
+      // ---- shade the lanes whose walk has finished
+      if (tr.node == -1) {
+        bool ended;
+        V3 radiance = mk(0, 0, 0);
+        if (tr.best_slot >= 0 && tr.best_t > 0.0f) {
+          ended = !shade_hit<COUNT>(P, path, tr.best_t, tr.best_slot, rng, c, radiance);
+          if (!ended) {
+            bounce++;
+            if (bounce >= P.max_depth) ended = true;        // depth exhausted: black (K:981)
+          }
+        } else {
+          radiance = shade_miss<COUNT>(P, path, c);
+          ended = true;
+        }
+        if (ended) {
+          color = color + radiance;
+          sample++;
+          tr.node = -2;
+        } else {
+          trav_begin(tr);
+          inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
+          if (COUNT) c.rays++;
+        }
+      }
+      // ---- lanes between paths: next sample of the same pixel, or store and take a new pixel
+      bool want_pixel = false;
+      if (tr.node == -2) {
+        if (px >= 0 && (float)sample < P.spp_f && !degenerate) {
+          // same pixel, next sample (K:1059)
+        } else {
+          if (px >= 0) {
+            store_pixel(P, px, py, color);
+            if (pixel_cost) pixel_cost[pcode] = steps;
+          }
+          px = -1;
+          want_pixel = true;
+        }
+      }
+      unsigned long long need = __ballot(want_pixel);
+      while (need != 0ull) {
+        if (cur_next >= 64) {                      // wave-uniform: fetch the next tile
+          unsigned t = 0;
+          if (lane == 0) t = atomicAdd(tile_counter, 1u);
+          const int q = (int)__builtin_amdgcn_readfirstlane(t) + (int)gridDim.x * 4;   // positions 0 .. #waves-1 were the waves' first chunks
+          cur_tile = ntiles;
+          if (q < nwork) { const int tt = q / P.batch; cur_frame = q - tt * P.batch; cur_tile = tile_order ? tile_order[tt] : tt; }
+          cur_next = 0;
+        }
+        if (cur_tile >= ntiles) {                  // frame exhausted: retire the lanes still asking
+          if (want_pixel) { tr.node = -3; want_pixel = false; }
+          break;
+        }
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+        const int avail = 64 - cur_next;
+        if (want_pixel && rank < avail) {
+          const int l = cur_next + rank;
+          const int col = cur_tile / P.gy, by = cur_tile - col * P.gy;
+          px = (P.stripe_rem + col * P.stripe_mod) * 8 + (l >> 3);
+          py = by * 8 + (l & 7);
+          pcode = cur_tile * 64 + l;
+          frame = cur_frame;
+          steps = 0;
+          sample = 0;
+          color = mk(0, 0, 0);
+          want_pixel = false;
+        }
+        const int n = __popcll(need);
+        cur_next += n < avail ? n : avail;
+        need = __ballot(want_pixel);
+      }
+      // ---- start the next path of every lane that has a pixel and no path
+      if (tr.node == -2 && px >= 0) {
+        if (degenerate) {
+          sample = 0x7fffffff;                     // nothing to trace: the pixel is stored as 0 next round
+          if (COUNT) c.samples++;
+        } else {
+          rng.init(sample_seed(P, px, py, sample, frame));
+          if (COUNT) { c.samples++; c.rays++; }
+          camera_ray(P, px, py, rng, path.rayo, path.raydir);
+          path.atten = splat(1.0f);
+          bounce = 0;
+          trav_begin(tr);
+          inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
+        }
+      }
+      if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
+      if (__ballot(tr.node != -3) == 0ull) break;
+    }
+    // ---- one node step for every walking lane
+    if (tr.node >= 0) {
+      if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
+      trav_step<COUNT>(walk, path.rayo, path.raydir, inv, tr, c);
+      steps++;
+    }
+  }
+  if (COUNT && lane == 0) {
+    atomicAdd(&P.counters[8], __builtin_readcyclecounter() - t_begin);
+    atomicAdd(&P.counters[9], t_phase);
+    atomicAdd(&P.counters[10], n_iter);
+    atomicAdd(&P.counters[11], n_phase);
+  }
+  if (COUNT) {
+    unsigned v[8] = {c.rays, c.V, c.L, c.S, c.T, c.samples, c.trav_slots, c.ray_slots};
+    for (int k = 0; k < 8; k++) {
+      unsigned long long s = v[k];
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (lane == 0 && s) atomicAdd(&P.counters[k], s);
+    }
+  }
+}
+
+// Cost feedback for the persistent kernel: per-tile cost = the most node steps any of its pixels
+// took (the critical path of the tile), then tiles sorted by cost, most expensive first.
+__global__ __launch_bounds__(256) void tile_cost_kernel(const unsigned* __restrict__ pixel_cost, unsigned* __restrict__ tile_cost, int ntiles) {
+  int tile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tile >= ntiles) return;
+  unsigned v = pixel_cost[(size_t)tile * 64 + (threadIdx.x & 63)];
+  for (int off = 32; off > 0; off >>= 1) { unsigned o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
+  if ((threadIdx.x & 63) == 0) tile_cost[tile] = v;
+}
+// one workgroup: counting sort into ORDER_BUCKETS classes of 16 steps each, descending
+constexpr int ORDER_BUCKETS = 256;
+__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __restrict__ tile_cost, int* __restrict__ order, int ntiles) {
+  __shared__ unsigned hist[ORDER_BUCKETS];
+  __shared__ unsigned base[ORDER_BUCKETS];
+  for (int i = threadIdx.x; i < ORDER_BUCKETS; i += blockDim.x) hist[i] = 0;
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+    unsigned b = tile_cost[t] >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
+    atomicAdd(&hist[b], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int b = ORDER_BUCKETS - 1; b >= 0; b--) { base[b] = run; run += hist[b]; }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+    unsigned b = tile_cost[t] >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
+    unsigned pos = atomicAdd(&base[b], 1u);
+    order[pos] = t;
   }
 }
 
@@ -115,7 +316,7 @@ __global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, con
     int* stack = lds_stack + (threadIdx.x >> 6) * (ORDERED_STACK * 64) + (threadIdx.x & 63);
     h = closest_hit_ordered<false>(P.pairs, P.prims, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
   } else {
-    h = closest_hit_threaded<false>(P.nodes, P.prims, ld3(o + 3 * i), ld3(d + 3 * i), c);
+    h = closest_hit_threaded<false>(walk_rsrc(P), ld3(o + 3 * i), ld3(d + 3 * i), c);
   }
   t[i] = h.t; slot[i] = h.slot;
 }
@@ -130,7 +331,7 @@ struct dr_context {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // resident scene
-  DevNode* nodes = nullptr;
+  DevUnit* walk = nullptr; size_t walk_bytes = 0;
   DevPair* pairs = nullptr;
   DevPrim* prims = nullptr;
   DevShade* shade = nullptr;
@@ -143,9 +344,19 @@ struct dr_context {
   int32_t* accum = nullptr; size_t accum_elems = 0; int accW = 0, accH = 0;
   uint8_t* present = nullptr; size_t present_bytes = 0;
   unsigned long long* counters = nullptr;
+  unsigned* tile_counters = nullptr; int tile_cursor = 0; int num_cus = 256;
+  // cost feedback (persistent kernel): per-pixel cost of the last frame, per-tile cost, tile order
+  unsigned* pixel_cost = nullptr; unsigned* tile_cost = nullptr; int* tile_order = nullptr;
+  int order_capacity = 0;          // tiles the three buffers are sized for
+  bool order_valid = false;        // tile_order was computed for `order_key`
+  float order_key[16] = {0};       // settings13 + W, H, stripe of the frame the order belongs to
+  bool feedback = true;
   int stripe_mod = 1, stripe_rem = 0;
   int traversal = DR_TRAVERSAL_THREADED;
   bool count = false;
+  int variant = 4;          // kernel build variant (DOGERAY_VARIANT, tuning experiments)
+  float cur_settings[13] = {0};
+  int batch_frames = 8;     // frames per launch of the persistent kernel in dr_render_accumulate (DOGERAY_BATCH)
   dr_stats stats;
 };
 
@@ -197,14 +408,15 @@ inline int hf2i(float f) {
 // settings[13] -> per-launch constants.  The camera block is K:1016-1052, evaluated once on the
 // host (it is identical for every pixel) with the reference's float/double promotions.
 int make_params(dr_context* c, const float* st, int W, int H, float background, uint64_t seed, RenderParams& P) {
-  if (!c->nodes) { set_error("no scene uploaded"); return DR_ERR_INVALID; }
+  if (!c->walk) { set_error("no scene uploaded"); return DR_ERR_INVALID; }
   if (W <= 0 || H <= 0 || (size_t)W * (size_t)H > (size_t)1 << 28) { set_error("bad frame size"); return DR_ERR_INVALID; }
   const int div = hf2i(st[11]);
   if (div < 1) { set_error("divisor must be >= 1"); return DR_ERR_INVALID; }
   const int backtex = hf2i(st[12]);
   if (backtex >= c->n_tex) { set_error("backtex refers to a texture that is not loaded"); return DR_ERR_INVALID; }
   memset(&P, 0, sizeof(P));
-  P.nodes = c->nodes; P.pairs = c->pairs; P.prims = c->prims; P.shade = c->shade; P.tex = c->tex; P.texels = c->texels;
+  memcpy(c->cur_settings, st, sizeof(c->cur_settings));
+  P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims; P.shade = c->shade; P.tex = c->tex; P.texels = c->texels;
   P.counters = c->counters;
   float aspect = float(W / st[11]) / float(H / st[11]);           // K:1016 (int / float)
   float fov = (float)((double)st[8] * M_PI / 180);                // K:1020
@@ -234,22 +446,108 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   P.seed_stride = 8u * (unsigned)P.gx;                            // blockDim.x * gridDim.x, K:1065
   P.max_depth = hf2i(st[9]);
   P.backtex = backtex;
+  P.batch = 1;
+  P.batch_seed_stride = 0;
   return DR_OK;
+}
+
+template <int OCC>
+void launch_variant(dr_context* c, const RenderParams& P, dim3 grid) {
+  dim3 block(256);
+  const bool ordered = c->traversal == DR_TRAVERSAL_ORDERED;
+  if (c->count) {
+    if (ordered) hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_ORDERED, OCC>), grid, block, 0, c->stream, P);
+    else hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_THREADED, OCC>), grid, block, 0, c->stream, P);
+  } else {
+    if (ordered) hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_ORDERED, OCC>), grid, block, 0, c->stream, P);
+    else hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_THREADED, OCC>), grid, block, 0, c->stream, P);
+  }
+}
+
+constexpr int TILE_COUNTERS = 1024;
+
+template <int OCC, int TRAV_MIN>
+void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pixel_cost) {
+  int work = P.ncols * P.gy * P.batch;
+  int blocks = c->num_cus * OCC;                   // OCC waves per SIMD on every CU
+  if (blocks * 4 > work) blocks = (work + 3) / 4;
+  dim3 grid((unsigned)blocks), block(256);
+  if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
+  else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
+}
+
+// Is the stored tile order for this view?  (Same settings, size and stripe: progressive frames.)
+bool order_matches(dr_context* c, const RenderParams& P, const float* key) {
+  return c->order_valid && memcmp(c->order_key, key, sizeof(c->order_key)) == 0;
+}
+
+// enqueue one frame (no events, no sync)
+void enqueue_frame(dr_context* c, const RenderParams& P) {
+  int tiles = P.ncols * P.gy;
+  if (c->variant >= 1000 && c->traversal == DR_TRAVERSAL_THREADED) {
+    // persistent kernel: 1OTT = OCC O (4, 6, 8), TRAV_MIN TT
+    if (c->tile_cursor >= TILE_COUNTERS) {
+      (void)hipMemsetAsync(c->tile_counters, 0, TILE_COUNTERS * sizeof(unsigned), c->stream);
+      c->tile_cursor = 0;
+    }
+    unsigned* counter = c->tile_counters + c->tile_cursor++;
+    // cost feedback buffers
+    const int* order = nullptr;
+    unsigned* pcost = nullptr;
+    if (c->feedback) {
+      if (c->order_capacity < tiles) {
+        for (void* b : {(void*)c->pixel_cost, (void*)c->tile_cost, (void*)c->tile_order}) if (b) (void)hipFree(b);
+        c->pixel_cost = nullptr; c->tile_cost = nullptr; c->tile_order = nullptr; c->order_capacity = 0; c->order_valid = false;
+        if (hipMalloc((void**)&c->pixel_cost, (size_t)tiles * 64 * sizeof(unsigned)) == hipSuccess &&
+            hipMalloc((void**)&c->tile_cost, (size_t)tiles * sizeof(unsigned)) == hipSuccess &&
+            hipMalloc((void**)&c->tile_order, (size_t)tiles * sizeof(int)) == hipSuccess)
+          c->order_capacity = tiles;
+      }
+      if (c->order_capacity >= tiles) {
+        float key[16] = {0};
+        memcpy(key, c->cur_settings, 13 * sizeof(float));
+        key[13] = (float)P.W; key[14] = (float)P.H; key[15] = (float)(P.stripe_mod * 1024 + P.stripe_rem);
+        if (order_matches(c, P, key)) order = c->tile_order;
+        else { memcpy(c->order_key, key, sizeof(key)); c->order_valid = false; }
+        pcost = c->pixel_cost;
+      }
+    }
+#define DR_LAUNCH_P(O, T) launch_persistent<O, T>(c, P, counter, order, pcost)
+    switch (c->variant) {
+      case 1432: DR_LAUNCH_P(4, 32); break;
+      case 1448: DR_LAUNCH_P(4, 48); break;
+      case 1464: DR_LAUNCH_P(4, 64); break;
+      case 1632: DR_LAUNCH_P(6, 32); break;
+      case 1648: DR_LAUNCH_P(6, 48); break;
+      case 1656: DR_LAUNCH_P(6, 56); break;
+      case 1664: DR_LAUNCH_P(6, 64); break;
+      case 1832: DR_LAUNCH_P(8, 32); break;
+      case 1848: DR_LAUNCH_P(8, 48); break;
+      case 1856: DR_LAUNCH_P(8, 56); break;
+      case 1864: DR_LAUNCH_P(8, 64); break;
+      default: DR_LAUNCH_P(6, 48); break;
+    }
+#undef DR_LAUNCH_P
+    if (pcost) {   // next frame's order from this frame's costs (stream-ordered, no host sync)
+      hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);
+      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, tiles);
+      c->order_valid = true;
+    }
+    return;
+  }
+  dim3 grid((unsigned)((tiles + 3) / 4));
+  switch (c->variant) {
+    case 6: launch_variant<6>(c, P, grid); break;
+    case 8: launch_variant<8>(c, P, grid); break;
+    default: launch_variant<4>(c, P, grid); break;
+  }
 }
 
 int launch_render(dr_context* c, const RenderParams& P) {
   int tiles = P.ncols * P.gy;
   if (tiles <= 0) return DR_OK;
-  dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  const bool ordered = c->traversal == DR_TRAVERSAL_ORDERED;
-  if (c->count) {
-    if (ordered) hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P);
-    else hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P);
-  } else {
-    if (ordered) hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P);
-    else hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P);
-  }
+  enqueue_frame(c, P);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   return DR_OK;
@@ -293,10 +591,23 @@ int dr_context_create(int device_ordinal, dr_context** out) {
   HIP_TRY(hipSetDevice(device_ordinal));
   dr_context* c = new dr_context();
   c->device = device_ordinal;
+  if (const char* v = getenv("DOGERAY_VARIANT")) c->variant = atoi(v);
+  if (const char* v = getenv("DOGERAY_FEEDBACK")) c->feedback = atoi(v) != 0;
+  if (const char* v = getenv("DOGERAY_BATCH")) c->batch_frames = atoi(v) > 0 ? atoi(v) : 1;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+  }
+  if (hipMalloc((void**)&c->tile_counters, TILE_COUNTERS * sizeof(unsigned)) != hipSuccess ||
+      hipMemset(c->tile_counters, 0, TILE_COUNTERS * sizeof(unsigned)) != hipSuccess) {
+    set_error("cannot allocate tile counters");
+    dr_context_destroy(c);
+    return DR_ERR_DEVICE;
+  }
   memset(&c->stats, 0, sizeof(c->stats));
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-      hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void**)&c->counters, 8 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)) != hipSuccess) {
+      hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemset(c->counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess) {
     set_error("cannot create stream/events");
     dr_context_destroy(c);
     return DR_ERR_DEVICE;
@@ -309,7 +620,7 @@ void dr_context_destroy(dr_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* bufs[] = {c->nodes, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters};
+  void* bufs[] = {c->walk, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -323,7 +634,8 @@ int dr_context_upload_scene(dr_context* c, const dr_scene* s) {
   DeviceImage img;
   int rc = linearise(s->host, img);
   if (rc != DR_OK) return rc;
-  if ((rc = upload(c->nodes, img.nodes)) != DR_OK) return rc;
+  if ((rc = upload(c->walk, img.walk)) != DR_OK) return rc;
+  c->walk_bytes = img.walk.size() * sizeof(DevUnit);
   if ((rc = upload(c->pairs, img.pairs)) != DR_OK) return rc;
   if ((rc = upload(c->prims, img.prims)) != DR_OK) return rc;
   if ((rc = upload(c->shade, img.shade)) != DR_OK) return rc;
@@ -346,7 +658,7 @@ int dr_context_set_stripe(dr_context* c, int mod, int rem) {
 
 int dr_context_set_traversal(dr_context* c, int mode) {
   if (!c || (mode != DR_TRAVERSAL_THREADED && mode != DR_TRAVERSAL_ORDERED)) { set_error("unknown traversal mode"); return DR_ERR_INVALID; }
-  if (mode == DR_TRAVERSAL_ORDERED && c->nodes && c->tree_depth > ORDERED_STACK) {
+  if (mode == DR_TRAVERSAL_ORDERED && c->walk && c->tree_depth > ORDERED_STACK) {
     set_error("ordered traversal supports at most 2^24 primitives");
     return DR_ERR_SCENE;
   }
@@ -368,6 +680,7 @@ int dr_render_frame(dr_context* c, const float settings13[13], int W, int H, flo
   P.out = c->frame;
   P.accumulate = 0;
   if ((rc = launch_render(c, P)) != DR_OK) return rc;
+  c->stats.launches += 1;
   uint64_t samples = (uint64_t)P.ncols * P.gy * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0);
   if ((rc = collect_time(c, 1, samples)) != DR_OK) return rc;
   if (out_int3) {
@@ -403,19 +716,20 @@ int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H
   P.accumulate = 1;
   int tiles = P.ncols * P.gy;
   if (tiles <= 0) return DR_OK;
-  dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-  const bool ordered = c->traversal == DR_TRAVERSAL_ORDERED;
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
-  for (int k = 0; k < nframes; k++) {
+  // The persistent kernel renders the frames in batches of `batch_frames` per launch (one work
+  // queue over all their tiles, atomic accumulation); the per-tile kernel takes one frame per launch.
+  const int per_launch = (c->variant >= 1000 && c->traversal == DR_TRAVERSAL_THREADED && c->batch_frames > 1) ? c->batch_frames : 1;
+  uint64_t launches = 0;
+  for (int k = 0; k < nframes; k += per_launch) {
     P.seed = frame_seed + (uint64_t)k * seed_stride;
-    if (c->count) {
-      if (ordered) hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P);
-      else hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P);
-    } else {
-      if (ordered) hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P);
-      else hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P);
-    }
+    P.batch = nframes - k < per_launch ? nframes - k : per_launch;
+    P.batch_seed_stride = seed_stride;
+    P.accumulate = P.batch > 1 ? 2 : 1;
+    enqueue_frame(c, P);
+    launches++;
   }
+  c->stats.launches += launches;
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
   uint64_t samples = (uint64_t)tiles * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0) * (uint64_t)nframes;
@@ -467,7 +781,7 @@ int dr_stats_reset(dr_context* c) {
   if (!c) { set_error("null context"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemset(c->counters, 0, 8 * sizeof(unsigned long long)));
+  HIP_TRY(hipMemset(c->counters, 0, 16 * sizeof(unsigned long long)));
   memset(&c->stats, 0, sizeof(c->stats));
   return DR_OK;
 }
@@ -476,12 +790,13 @@ int dr_stats_get(dr_context* c, dr_stats* out) {
   if (!c || !out) { set_error("null argument"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  unsigned long long h[8];
+  unsigned long long h[16];
   HIP_TRY(hipMemcpy(h, c->counters, sizeof(h), hipMemcpyDeviceToHost));
   *out = c->stats;
   out->rays = h[0]; out->node_visits = h[1]; out->prim_tests = h[2]; out->shades = h[3]; out->texels = h[4];
   if (c->count) out->samples = h[5];
   out->trav_slots = h[6]; out->ray_slots = h[7];
+  for (int k = 0; k < 4; k++) out->diag[k] = h[8 + k];
   return DR_OK;
 }
 
@@ -550,14 +865,14 @@ int dr_kat_optics(dr_context* c, int n, const float* v, const float* nrm, const 
 
 int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx) {
   KAT_PRE(n);
-  if (!c->nodes) { set_error("no scene uploaded"); return DR_ERR_INVALID; }
+  if (!c->walk) { set_error("no scene uploaded"); return DR_ERR_INVALID; }
   DevBuf<float> bo, bd, bt; DevBuf<int32_t> bs;
   size_t m = (size_t)n * 3;
   KAT_DO(bo.alloc(m)); KAT_DO(bd.alloc(m)); KAT_DO(bt.alloc((size_t)n)); KAT_DO(bs.alloc((size_t)n));
   KAT_DO(bo.put(o, m)); KAT_DO(bd.put(d, m));
   RenderParams P;
   memset(&P, 0, sizeof(P));
-  P.nodes = c->nodes; P.pairs = c->pairs; P.prims = c->prims;
+  P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims;
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (c->traversal == DR_TRAVERSAL_ORDERED) hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p);
   else hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p);

@@ -99,25 +99,18 @@ __device__ __forceinline__ V3 rand_in_unit_disk(Xorwow& r) {     // K:988-994
 // grows, t_max only shrinks and neither can become NaN, so "t_max <= t_min after some axis"
 // and "t_max <= t_min after the last axis" are the same predicate.
 __device__ __forceinline__ bool slab(V3 o, V3 inv, const float mn[3], const float mx[3], float& dist) {
-  float t_min = 0, t_max = 10000;
-  {
-    float t0 = (mn[0] - o.x) * inv.x, t1 = (mx[0] - o.x) * inv.x;
-    if (inv.x < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-    t_min = t0 > t_min ? t0 : t_min;
-    t_max = t1 < t_max ? t1 : t_max;
-  }
-  {
-    float t0 = (mn[1] - o.y) * inv.y, t1 = (mx[1] - o.y) * inv.y;
-    if (inv.y < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-    t_min = t0 > t_min ? t0 : t_min;
-    t_max = t1 < t_max ? t1 : t_max;
-  }
-  {
-    float t0 = (mn[2] - o.z) * inv.z, t1 = (mx[2] - o.z) * inv.z;
-    if (inv.z < 0.0f) { float s = t0; t0 = t1; t1 = s; }
-    t_min = t0 > t_min ? t0 : t_min;
-    t_max = t1 < t_max ? t1 : t_max;
-  }
+  // The reference swaps (t0, t1) when invD < 0, i.e. the plane entered first is max for a
+  // negative direction: select the planes first (same products afterwards).  "x > m ? x : m" with
+  // m never NaN is fmax(x, m) (a NaN x is ignored either way; the sign of a zero result feeds
+  // comparisons only), so the three-axis chain folds into max3 / min3.
+  float nx = inv.x < 0.0f ? mx[0] : mn[0], fx = inv.x < 0.0f ? mn[0] : mx[0];
+  float ny = inv.y < 0.0f ? mx[1] : mn[1], fy = inv.y < 0.0f ? mn[1] : mx[1];
+  float nz = inv.z < 0.0f ? mx[2] : mn[2], fz = inv.z < 0.0f ? mn[2] : mx[2];
+  float t0x = (nx - o.x) * inv.x, t1x = (fx - o.x) * inv.x;
+  float t0y = (ny - o.y) * inv.y, t1y = (fy - o.y) * inv.y;
+  float t0z = (nz - o.z) * inv.z, t1z = (fz - o.z) * inv.z;
+  float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0x, 0.0f), t0y), t0z);
+  float t_max = __builtin_fminf(__builtin_fminf(__builtin_fminf(t1x, 10000.0f), t1y), t1z);
   dist = t_min;
   return t_max > t_min;
 }
@@ -154,10 +147,8 @@ __device__ __forceinline__ float sphere_hit(V3 c, float radius, V3 o, V3 d) {
   return (-half_b - __builtin_sqrtf(disc)) / a;
 }
 
-// singlehit K:432-464 on one DevPrim; returns t or -1
-__device__ __forceinline__ float prim_hit(const DevPrim* __restrict__ prims, int slot, V3 o, V3 d) {
-  const float4* p = reinterpret_cast<const float4*>(prims + slot);
-  float4 A = p[0], B = p[1], C = p[2];
+// singlehit K:432-464 on one primitive record (three 16-byte units); returns t or -1
+__device__ __forceinline__ float prim_hit_regs(float4 A, float4 B, float4 C, V3 o, V3 d) {
   int type = __float_as_int(C.y);
   float dist = -1.0f;
   if (type == 2) dist = tri_hit(o, d, mk(A.x, A.y, A.z), mk(A.w, B.x, B.y), mk(B.z, B.w, C.x));
@@ -165,43 +156,78 @@ __device__ __forceinline__ float prim_hit(const DevPrim* __restrict__ prims, int
   if (dist < 10000.0f && dist > -0.0f) return dist;          // K:449
   return -1.0f;
 }
+__device__ __forceinline__ float prim_hit(const DevPrim* __restrict__ prims, int slot, V3 o, V3 d) {
+  const float4* p = reinterpret_cast<const float4*>(prims + slot);
+  return prim_hit_regs(p[0], p[1], p[2], o, d);
+}
 
 struct Hit { float t; int slot; };
 
 struct Ctr { unsigned rays, V, L, S, T, samples, trav_slots, ray_slots; };   // *_slots: 64 per wave-level iteration / query (SIMD efficiency probes)
 
-// hit() K:468-512, the reference's order: a node that is entered continues with node + 1
-// (pre-order numbering), a node that is skipped, and every leaf, continues with its miss link.
+// hit() K:468-512 in the reference's order, over the walk array (device_layout.h): a node that
+// is entered continues with its hit link (its first child), a node that is skipped, and every
+// leaf, with its miss link.  The link says whether its target is a leaf, so a leaf's box and
+// primitive are fetched together and the triangle test costs no second memory round trip.
+// The loop body is its own function so that the persistent kernel can interleave node steps of
+// different rays (lanes re-armed while their neighbours are still walking).
+struct Trav { int node; float best_t; int best_slot; };   // node: link to visit next, < 0 = walk finished
+
+__device__ __forceinline__ void trav_begin(Trav& tr) { tr.node = 0; tr.best_t = 10000000.0f; tr.best_slot = -1; }
+
+// The walk array is read through a buffer descriptor with 128-bit buffer loads: the compiler may
+// not re-slice those into narrower / unaligned pieces (it does so with plain float4 loads: the box
+// came in as dwordx2 + unaligned dwordx4 + dwordx3), so a node costs exactly two 16-byte requests
+// and a leaf five, all issued before the first wait.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t WalkRsrc;
+__device__ __forceinline__ WalkRsrc walk_rsrc(const RenderParams& P) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)P.walk, 0, (int)P.walk_bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ld_unit(WalkRsrc r, unsigned byte_off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit_threaded(const DevNode* __restrict__ nodes, const DevPrim* __restrict__ prims,
-                                                    V3 o, V3 d, Ctr& c) {
-  Hit best; best.t = 10000000.0f; best.slot = -1;
-  V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  int node = 0;
-  if (COUNT) { c.rays++; if (__lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u) c.ray_slots += 64; }
-  while (node >= 0) {
-    if (COUNT) { if (__lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u) c.trav_slots += 64; }
-    const float4* np = reinterpret_cast<const float4*>(nodes + node);
-    float4 A = np[0], B = np[1];
-    float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
-    int prim = __float_as_int(A.w), miss = __float_as_int(B.w);
-    float dist;
-    if (COUNT) c.V++;
-    bool h = slab(o, inv, mn, mx, dist);
-    if (h && dist < best.t) {
-      if (prim >= 0) {
-        if (COUNT) c.L++;
-        float t = prim_hit(prims, prim, o, d);
-        if (t > -0.01f && t < best.t) { best.t = t; best.slot = prim; }   // K:488 (t is -1 or > 0)
-        node = miss;
-      } else {
-        node = node + 1;
-      }
+__device__ __forceinline__ void trav_step(WalkRsrc walk, V3 o, V3 d, V3 inv, Trav& tr, Ctr& c) {
+  const bool leaf = tr.node & 1;
+  const unsigned off = (unsigned)(tr.node >> 1) << 4;
+  float4 A = ld_unit(walk, off), B = ld_unit(walk, off + 16);
+  float4 P0 = A, P1 = A, P2 = A;
+  if (leaf) { P0 = ld_unit(walk, off + 32); P1 = ld_unit(walk, off + 48); P2 = ld_unit(walk, off + 64); }
+  float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
+  const int w0 = __float_as_int(A.w), miss = __float_as_int(B.w);
+  float dist;
+  if (COUNT) c.V++;
+  bool h = slab(o, inv, mn, mx, dist);
+  if (h && dist < tr.best_t) {
+    if (leaf) {
+      if (COUNT) c.L++;
+      float t = prim_hit_regs(P0, P1, P2, o, d);
+      if (t > -0.01f && t < tr.best_t) { tr.best_t = t; tr.best_slot = w0; }   // K:488 (t is -1 or > 0)
+      tr.node = miss;
     } else {
-      node = miss;
+      tr.node = w0;
     }
+  } else {
+    tr.node = miss;
   }
-  if (best.slot < 0) best.t = -1.0f;
+}
+
+__device__ __forceinline__ bool first_active_lane() { return __lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u; }
+
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_threaded(WalkRsrc walk, V3 o, V3 d, Ctr& c) {
+  Trav tr;
+  trav_begin(tr);
+  V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  if (COUNT) { c.rays++; if (first_active_lane()) c.ray_slots += 64; }
+  while (tr.node >= 0) {
+    if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
+    trav_step<COUNT>(walk, o, d, inv, tr, c);
+  }
+  Hit best; best.t = tr.best_slot < 0 ? -1.0f : tr.best_t; best.slot = tr.best_slot;
   return best;
 }
 
@@ -314,157 +340,193 @@ __device__ __forceinline__ V3 rgb_of(uint32_t px) {
   return mk(float(px & 255u) / 255, float((px >> 8) & 255u) / 255, float((px >> 16) & 255u) / 255);
 }
 
-// One path: raycolor K:787-982.  CLOSEST is the traversal functor.
+// raycolor K:787-982 is split at its natural seams so that the per-pixel kernel and the
+// persistent kernel run the same arithmetic: shade_hit = the "hit > 0" branch of one bounce
+// (K:807-950), shade_miss = the background branch (K:951-976).
+struct Path { V3 rayo, raydir, atten; };
+
+// Returns true when the path continues (rayo/raydir/atten updated), false when it ends at an
+// emissive surface with `emitted` as its radiance (K:941-944).
+template <bool COUNT>
+__device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, float t, int slot, Xorwow& rng, Ctr& c, V3& emitted) {
+  V3& rayo = path.rayo; V3& raydir = path.raydir; V3& atten = path.atten;
+  if (COUNT) c.S++;
+  V3 hitpoint = rayo + splat(t) * raydir;
+  // ---- getnormal K:703-773
+  const float4* pp = reinterpret_cast<const float4*>(P.prims + slot);
+  const float4* sp = reinterpret_cast<const float4*>(P.shade + slot);
+  float4 pA = pp[0], pB = pp[1], pC = pp[2];
+  float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
+  int type = __float_as_int(pC.y);
+  V3 texco = mk(0, 0, 0);
+  V3 N;
+  if (type == 0) {
+    N = (hitpoint - mk(pA.x, pA.y, pA.z)) / splat(pA.w);
+  } else if (type == 2) {
+    V3 v0 = mk(pA.x, pA.y, pA.z), v0v1 = mk(pA.w, pB.x, pB.y), v0v2 = mk(pB.z, pB.w, pC.x);
+    N = cross(v0v1, v0v2);
+    V3 pvec = cross(raydir, v0v2);
+    float det = dot(v0v1, pvec);
+    float invDet = 1 / det;
+    V3 tvec = rayo - v0;
+    float ux = dot(tvec, pvec) * invDet;
+    V3 qvec = cross(tvec, v0v1);
+    float uy = dot(raydir, qvec) * invDet;
+    float uz = 1 - ux - uy;
+    // texco = uz*t1 + ux*t2 + uy*t3 (the z components of t1..t3 are never read again)
+    texco.x = uz * s3.x + ux * s3.z + uy * s4.x;
+    texco.y = uz * s3.y + ux * s3.w + uy * s4.y;
+    V3 fn = mk(s0.x, s0.y, s0.z);
+    if (fn.z != -20) {
+      N = fn;
+      int flags = __float_as_int(s6.z);
+      if (s1.y != -20 && (flags & 1)) {     // n1.z
+        V3 n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x), n3 = mk(s2.y, s2.z, s2.w);
+        N = splat(uz) * n1 + splat(ux) * n2 + splat(uy) * n3;
+      }
+    }
+    N = normalized(N);
+  } else {
+    N = normalized(hitpoint - mk(pA.x, pA.y, pA.z));
+  }
+  bool front = dot(raydir, N) < 0;
+  N = front ? N : N * splat(-1.0f);
+  // ---- material inputs K:826-844
+  V3 col = mk(s4.z, s4.w, s5.x);
+  float add_x = s5.y, rough = s5.z;
+  int mat = __float_as_int(s5.w), texnum = __float_as_int(s6.x), rtexnum = __float_as_int(s6.y);
+  int flags = __float_as_int(s6.z);
+  V3 ocolor = col;
+  if (texnum >= 0) {
+    ocolor = rgb_of(tex_fetch<COUNT>(P.tex, P.texels, texnum, texco.x, -texco.y + 1, c));
+  } else if (flags & 2) {                     // checker K:776-784
+    float u2 = __builtin_floorf(texco.x * 10), v2 = __builtin_floorf(texco.y * 10);
+    float yes = u2 + v2;
+    ocolor = (__builtin_fmodf(yes, 2.0f) == 0) ? splat(0.8f) : col;
+  }
+  if (rtexnum >= 0) {
+    uint32_t px = tex_fetch<COUNT>(P.tex, P.texels, rtexnum, texco.x, -texco.y + 1, c);
+    rough = float(px & 255u) / 255 / 2;
+  }
+  // ---- scatter K:848-944
+  if (mat == 0) {
+    V3 target = hitpoint + N;
+    if (add_x == 0) target = target + rand_in_unit_sphere(rng);
+    else target = target + normalized(rand_in_unit_sphere(rng));
+    atten = atten * ocolor;
+    rayo = hitpoint;
+    raydir = normalized(target - hitpoint);
+  } else if (mat == 2) {
+    atten = atten * ocolor;
+    rayo = hitpoint;
+    raydir = reflect(normalized(raydir), N);
+  } else if (mat == 3) {
+    V3 refl = reflect(normalized(raydir), N);
+    atten = atten * ocolor;
+    rayo = hitpoint;
+    raydir = refl + splat(rough) * rand_in_unit_sphere(rng);
+  } else if (mat == 5) {
+    float r = randy(rng);
+    if (r > 0.8) {                           // float compared with the double 0.8
+      V3 refl = reflect(normalized(raydir), N);
+      atten = atten * ocolor;
+      rayo = hitpoint;
+      raydir = refl + splat(rough) * rand_in_unit_sphere(rng);
+    } else {
+      V3 target = hitpoint + N;
+      target = target + rand_in_unit_sphere(rng);
+      atten = atten * ocolor;
+      rayo = hitpoint;
+      raydir = normalized(target - hitpoint);
+    }
+  } else if (mat == 4) {
+    float ir = s5.z;                         // b[g].addional.y itself, not the textured roughness (K:917)
+    float ratio = front ? (1.0f / ir) : ir;
+    float cos_theta = (float)fmin((double)dot(normalized(raydir) * splat(-1.0f), N), 1.0);
+    float sin_theta = (float)__builtin_sqrt(1.0 - (double)(cos_theta * cos_theta));
+    bool cannot = (ratio * sin_theta) > 1.0f;
+    V3 out;
+    if (cannot || reflectance(cos_theta, ratio) > randy(rng)) out = reflect(normalized(raydir), N);
+    else out = refract(normalized(raydir), N, ratio);
+    atten = atten * ocolor;
+    rayo = hitpoint;
+    raydir = out;
+  } else {
+    { emitted = ocolor * atten; return false; }
+  }
+  return true;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ V3 shade_miss(const RenderParams& P, const Path& path, Ctr& c) {
+  const V3 raydir = path.raydir, atten = path.atten;
+  V3 u = normalized(raydir);
+  if (P.backtex > -1) {                       // K:953-966
+    double ux = (double)u.x, uy = (double)u.y, uz = (double)u.z + 1.;
+    float m = (float)(2. * __builtin_sqrt(ux * ux + uy * uy + uz * uz));
+    V3 tt = u / splat(m) + splat(.5f);
+    tt.y = -tt.y;
+    V3 colr = rgb_of(tex_fetch<COUNT>(P.tex, P.texels, P.backtex, tt.x, -tt.y + 1, c));
+    return atten * colr * splat(P.bgint);
+  }
+  float t2 = (float)(0.5 * ((double)u.y + 1.0));   // K:971-974
+  float omt = (float)(1.0 - (double)t2);
+  V3 sky = splat(omt) * mk(1.0f, 1.0f, 1.0f) + splat(t2) * mk(0.5f, 0.7f, 1.0f);
+  return atten * sky * splat(P.bgint);
+}
+
+// One path: raycolor K:787-982.  `closest` is the traversal functor.
 template <bool COUNT, class Closest>
 __device__ __forceinline__ V3 trace_path(const RenderParams& P, const Closest& closest, V3 origin, V3 dir, Xorwow& rng, Ctr& c) {
-  V3 raydir = dir, rayo = origin, atten = splat(1.0f);
+  Path path; path.rayo = origin; path.raydir = dir; path.atten = splat(1.0f);
   for (int i = 0; i < P.max_depth; i++) {
-    Hit h = closest(rayo, raydir, c);
-    float t = h.t;
-    if (t > 0.0f) {
-      if (COUNT) c.S++;
-      V3 hitpoint = rayo + splat(t) * raydir;
-      // ---- getnormal K:703-773
-      const float4* pp = reinterpret_cast<const float4*>(P.prims + h.slot);
-      const float4* sp = reinterpret_cast<const float4*>(P.shade + h.slot);
-      float4 pA = pp[0], pB = pp[1], pC = pp[2];
-      float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
-      int type = __float_as_int(pC.y);
-      V3 texco = mk(0, 0, 0);
-      V3 N;
-      if (type == 0) {
-        N = (hitpoint - mk(pA.x, pA.y, pA.z)) / splat(pA.w);
-      } else if (type == 2) {
-        V3 v0 = mk(pA.x, pA.y, pA.z), v0v1 = mk(pA.w, pB.x, pB.y), v0v2 = mk(pB.z, pB.w, pC.x);
-        N = cross(v0v1, v0v2);
-        V3 pvec = cross(raydir, v0v2);
-        float det = dot(v0v1, pvec);
-        float invDet = 1 / det;
-        V3 tvec = rayo - v0;
-        float ux = dot(tvec, pvec) * invDet;
-        V3 qvec = cross(tvec, v0v1);
-        float uy = dot(raydir, qvec) * invDet;
-        float uz = 1 - ux - uy;
-        // texco = uz*t1 + ux*t2 + uy*t3 (the z components of t1..t3 are never read again)
-        texco.x = uz * s3.x + ux * s3.z + uy * s4.x;
-        texco.y = uz * s3.y + ux * s3.w + uy * s4.y;
-        V3 fn = mk(s0.x, s0.y, s0.z);
-        if (fn.z != -20) {
-          N = fn;
-          int flags = __float_as_int(s6.z);
-          if (s1.y != -20 && (flags & 1)) {     // n1.z
-            V3 n1 = mk(s0.w, s1.x, s1.y), n2 = mk(s1.z, s1.w, s2.x), n3 = mk(s2.y, s2.z, s2.w);
-            N = splat(uz) * n1 + splat(ux) * n2 + splat(uy) * n3;
-          }
-        }
-        N = normalized(N);
-      } else {
-        N = normalized(hitpoint - mk(pA.x, pA.y, pA.z));
-      }
-      bool front = dot(raydir, N) < 0;
-      N = front ? N : N * splat(-1.0f);
-      // ---- material inputs K:826-844
-      V3 col = mk(s4.z, s4.w, s5.x);
-      float add_x = s5.y, rough = s5.z;
-      int mat = __float_as_int(s5.w), texnum = __float_as_int(s6.x), rtexnum = __float_as_int(s6.y);
-      int flags = __float_as_int(s6.z);
-      V3 ocolor = col;
-      if (texnum >= 0) {
-        ocolor = rgb_of(tex_fetch<COUNT>(P.tex, P.texels, texnum, texco.x, -texco.y + 1, c));
-      } else if (flags & 2) {                     // checker K:776-784
-        float u2 = __builtin_floorf(texco.x * 10), v2 = __builtin_floorf(texco.y * 10);
-        float yes = u2 + v2;
-        ocolor = (__builtin_fmodf(yes, 2.0f) == 0) ? splat(0.8f) : col;
-      }
-      if (rtexnum >= 0) {
-        uint32_t px = tex_fetch<COUNT>(P.tex, P.texels, rtexnum, texco.x, -texco.y + 1, c);
-        rough = float(px & 255u) / 255 / 2;
-      }
-      // ---- scatter K:848-944
-      if (mat == 0) {
-        V3 target = hitpoint + N;
-        if (add_x == 0) target = target + rand_in_unit_sphere(rng);
-        else target = target + normalized(rand_in_unit_sphere(rng));
-        atten = atten * ocolor;
-        rayo = hitpoint;
-        raydir = normalized(target - hitpoint);
-      } else if (mat == 2) {
-        atten = atten * ocolor;
-        rayo = hitpoint;
-        raydir = reflect(normalized(raydir), N);
-      } else if (mat == 3) {
-        V3 refl = reflect(normalized(raydir), N);
-        atten = atten * ocolor;
-        rayo = hitpoint;
-        raydir = refl + splat(rough) * rand_in_unit_sphere(rng);
-      } else if (mat == 5) {
-        float r = randy(rng);
-        if (r > 0.8) {                           // float compared with the double 0.8
-          V3 refl = reflect(normalized(raydir), N);
-          atten = atten * ocolor;
-          rayo = hitpoint;
-          raydir = refl + splat(rough) * rand_in_unit_sphere(rng);
-        } else {
-          V3 target = hitpoint + N;
-          target = target + rand_in_unit_sphere(rng);
-          atten = atten * ocolor;
-          rayo = hitpoint;
-          raydir = normalized(target - hitpoint);
-        }
-      } else if (mat == 4) {
-        float ir = s5.z;                         // b[g].addional.y itself, not the textured roughness (K:917)
-        float ratio = front ? (1.0f / ir) : ir;
-        float cos_theta = (float)fmin((double)dot(normalized(raydir) * splat(-1.0f), N), 1.0);
-        float sin_theta = (float)__builtin_sqrt(1.0 - (double)(cos_theta * cos_theta));
-        bool cannot = (ratio * sin_theta) > 1.0f;
-        V3 out;
-        if (cannot || reflectance(cos_theta, ratio) > randy(rng)) out = reflect(normalized(raydir), N);
-        else out = refract(normalized(raydir), N, ratio);
-        atten = atten * ocolor;
-        rayo = hitpoint;
-        raydir = out;
-      } else {
-        return ocolor * atten;
-      }
+    Hit h = closest(path.rayo, path.raydir, c);
+    if (h.t > 0.0f) {
+      V3 emitted;
+      if (!shade_hit<COUNT>(P, path, h.t, h.slot, rng, c, emitted)) return emitted;
     } else {
-      V3 u = normalized(raydir);
-      if (P.backtex > -1) {                       // K:953-966
-        double ux = (double)u.x, uy = (double)u.y, uz = (double)u.z + 1.;
-        float m = (float)(2. * __builtin_sqrt(ux * ux + uy * uy + uz * uz));
-        V3 tt = u / splat(m) + splat(.5f);
-        tt.y = -tt.y;
-        V3 colr = rgb_of(tex_fetch<COUNT>(P.tex, P.texels, P.backtex, tt.x, -tt.y + 1, c));
-        return atten * colr * splat(P.bgint);
-      }
-      float t2 = (float)(0.5 * ((double)u.y + 1.0));   // K:971-974
-      float omt = (float)(1.0 - (double)t2);
-      V3 sky = splat(omt) * mk(1.0f, 1.0f, 1.0f) + splat(t2) * mk(0.5f, 0.7f, 1.0f);
-      return atten * sky * splat(P.bgint);
+      return shade_miss<COUNT>(P, path, c);
     }
   }
   return mk(0, 0, 0);
 }
 
+// Camera ray of one sample: K:1065-1073 (rng must be freshly seeded).
+__device__ __forceinline__ void camera_ray(const RenderParams& P, int x, int y, Xorwow& rng, V3& origin, V3& dir) {
+  V3 from = ld3(P.from), llc = ld3(P.llc), hor = ld3(P.hor), ver = ld3(P.ver), uu = ld3(P.uu), vu = ld3(P.vu);
+  float nu = (float)(((double)(float)x + rng.uniform_double()) / P.den_w);
+  float nv = (float)(((double)(float)y + rng.uniform_double()) / P.den_h);
+  V3 rd = splat(P.lens_radius) * rand_in_unit_disk(rng);
+  V3 offset = uu * splat(rd.x) + vu * splat(rd.y);
+  dir = llc + splat(nu) * hor + splat(nv) * ver - from - offset;
+  origin = from + offset;
+}
+__device__ __forceinline__ uint64_t sample_seed(const RenderParams& P, int x, int y, int s, int frame = 0) {   // K:1065 with clock() := frame seed
+  return P.seed + (uint64_t)frame * P.batch_seed_stride + (uint64_t)s * 0x9E3779B97F4A7C15ull +
+         (uint64_t)((uint32_t)x + (uint32_t)y * P.seed_stride);
+}
+__device__ __forceinline__ void store_pixel(const RenderParams& P, int x, int y, V3 color) {     // K:1081-1085
+  int r = f2i(color.x * 255 * P.scale), g = f2i(color.y * 255 * P.scale), b = f2i(color.z * 255 * P.scale);
+  int32_t* px = P.out + ((size_t)x * (size_t)P.H + (size_t)y) * 3;
+  if (P.accumulate == 2) {        // frames of one batch may finish the same pixel concurrently; integer adds commute
+    atomicAdd(px + 0, r); atomicAdd(px + 1, g); atomicAdd(px + 2, b);
+  } else if (P.accumulate) { px[0] += r; px[1] += g; px[2] += b; }
+  else { px[0] = r; px[1] = g; px[2] = b; }
+}
+
 // Kernel K:998-1093 for one pixel (the camera basis comes precomputed in P).
 template <bool COUNT, class Closest>
 __device__ __forceinline__ void render_pixel(const RenderParams& P, const Closest& closest, int x, int y, Ctr& c) {
-  V3 from = ld3(P.from), llc = ld3(P.llc), hor = ld3(P.hor), ver = ld3(P.ver), uu = ld3(P.uu), vu = ld3(P.vu);
   V3 color = mk(0, 0, 0);
   for (int s = 0; (float)s < P.spp_f; ++s) {
     Xorwow rng;
-    rng.init(P.seed + (uint64_t)s * 0x9E3779B97F4A7C15ull + (uint64_t)((uint32_t)x + (uint32_t)y * P.seed_stride));
+    rng.init(sample_seed(P, x, y, s));
     if (COUNT) c.samples++;
-    float nu = (float)(((double)(float)x + rng.uniform_double()) / P.den_w);
-    float nv = (float)(((double)(float)y + rng.uniform_double()) / P.den_h);
-    V3 rd = splat(P.lens_radius) * rand_in_unit_disk(rng);
-    V3 offset = uu * splat(rd.x) + vu * splat(rd.y);
-    V3 dir = llc + splat(nu) * hor + splat(nv) * ver - from - offset;
-    color = color + trace_path<COUNT>(P, closest, from + offset, dir, rng, c);
+    V3 origin, dir;
+    camera_ray(P, x, y, rng, origin, dir);
+    color = color + trace_path<COUNT>(P, closest, origin, dir, rng, c);
   }
-  int r = f2i(color.x * 255 * P.scale), g = f2i(color.y * 255 * P.scale), b = f2i(color.z * 255 * P.scale);
-  int32_t* px = P.out + ((size_t)x * (size_t)P.H + (size_t)y) * 3;
-  if (P.accumulate) { px[0] += r; px[1] += g; px[2] += b; }
-  else { px[0] = r; px[1] = g; px[2] = b; }
+  store_pixel(P, x, y, color);
 }
 
 }  // namespace dr

@@ -5,9 +5,12 @@
 // every frame (kernel.cu K:2618-2629).  Here the scene is uploaded once, renumbered and split
 // by access frequency:
 //
-//   nodes   32 B   {min.xyz, prim} {max.xyz, miss}      one record per node, DFS pre-order,
-//                                                        so "hit link" is always node + 1 and a
-//                                                        subtree is one contiguous range
+//   walk    16-B units, one record per node in DFS pre-order (a subtree is one contiguous range):
+//             internal  2 units  {min.xyz, hit link} {max.xyz, miss link}
+//             leaf      5 units  {min.xyz, slot}     {max.xyz, miss link} + its primitive (3 units)
+//           link = (unit index << 1) | target-is-leaf, -1 = end of the walk.  Knowing from the
+//           link that the target is a leaf lets the kernel fetch the box AND the triangle with
+//           one round trip instead of two dependent ones.
 //   pairs   64 B   both children of an internal node     (ordered traversal: one fetch per step)
 //   prims   48 B   {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, type, -, -}   hot intersection data,
 //                                                        in leaf (DFS) order: slot = leaf rank
@@ -21,12 +24,11 @@
 
 namespace dr {
 
-struct DevNode {       // 32 B, 32-B aligned
-  float mn[3];
-  int32_t prim;        // >= 0: leaf, slot of its primitive; -1: internal
-  float mx[3];
-  int32_t miss;        // node to continue with when this subtree is skipped / finished; -1 = end
+struct DevUnit {       // 16 B; the walk array is made of these (read as float4 on the device)
+  float f[4];
 };
+constexpr int WALK_UNITS_INTERNAL = 2;
+constexpr int WALK_UNITS_LEAF = 5;
 
 // Ordered traversal: record k describes the two children of internal node k (pre-order index
 // of the internal node among ALL nodes is kept in `DevNode`; pairs are indexed by node id).
@@ -70,7 +72,7 @@ struct DevTex {
   int32_t pad;
 };
 
-static_assert(sizeof(DevNode) == 32, "DevNode");
+static_assert(sizeof(DevUnit) == 16, "DevUnit");
 static_assert(sizeof(DevPair) == 64, "DevPair");
 static_assert(sizeof(DevPrim) == 48, "DevPrim");
 static_assert(sizeof(DevShade) == 128, "DevShade");
@@ -79,7 +81,9 @@ static_assert(sizeof(DevTex) == 16, "DevTex");
 // Everything one launch needs.  The camera basis (kernel.cu K:1016-1052) does not depend on
 // the pixel, so it is computed once on the host with the reference's arithmetic.
 struct RenderParams {
-  const DevNode* nodes;
+  const DevUnit* walk;
+  uint32_t walk_bytes;            // size of the walk array (buffer descriptor range; < 4 GiB)
+  uint32_t pad_;
   const DevPair* pairs;
   const DevPrim* prims;
   const DevShade* shade;
@@ -101,8 +105,9 @@ struct RenderParams {
   uint32_t seed_stride;           // blockDim.x * gridDim.x = 8 * gx (K:1065)
   int32_t max_depth;
   int32_t backtex;
-  int32_t accumulate;             // 0: store, 1: add into out
-  int32_t root_is_leaf;           // never (N >= 2), kept for clarity
+  int32_t accumulate;             // 0: store, 1: add into out, 2: atomic add (several frames in one launch)
+  int32_t batch;                  // frames rendered by this launch (persistent kernel), >= 1
+  uint64_t batch_seed_stride;     // frame f of the batch uses seed + f * batch_seed_stride
 };
 
 }  // namespace dr

@@ -9,7 +9,6 @@ int linearise(const HostScene& sc, DeviceImage& img) {
   const int N = sc.n;
   if (sc.bvh.empty() || sc.bvh_used != 2 * N - 1) { set_error("BVH not built"); return DR_ERR_INVALID; }
   const int used = sc.bvh_used;
-  img.nodes.assign((size_t)used, DevNode());
   img.pairs.assign((size_t)(N - 1), DevPair());
   img.prims.assign((size_t)N, DevPrim());
   img.shade.assign((size_t)N, DevShade());
@@ -49,18 +48,15 @@ int linearise(const HostScene& sc, DeviceImage& img) {
     }
   }
 
+  // pre-order checks: an internal node's first child is the next node, a leaf's hit link equals
+  // its miss link (K:1738-1739) and is the next node too
   for (int k = 0; k < used; k++) {
     const dr_bvh_node& b = sc.bvh[(size_t)order[(size_t)k]];
-    DevNode& d = img.nodes[(size_t)k];
-    memcpy(d.mn, b.min, sizeof(d.mn));
-    memcpy(d.mx, b.max, sizeof(d.mx));
-    d.prim = b.end ? slot_of[(size_t)order[(size_t)k]] : -1;
-    d.miss = b.miss_node < 0 ? -1 : new_id[(size_t)b.miss_node];
     if (!b.end && new_id[(size_t)b.children[0]] != k + 1) { set_error("pre-order numbering broken"); return DR_ERR_INVALID; }
     if (b.end) {
-      // a leaf's hit link equals its miss link (K:1738-1739) and is the next node in pre-order
       int expect = (k + 1 < used) ? k + 1 : -1;
-      if (d.miss != expect) { set_error("leaf link is not the pre-order successor"); return DR_ERR_INVALID; }
+      int miss = b.miss_node < 0 ? -1 : new_id[(size_t)b.miss_node];
+      if (miss != expect) { set_error("leaf link is not the pre-order successor"); return DR_ERR_INVALID; }
     }
   }
 
@@ -121,6 +117,28 @@ int linearise(const HostScene& sc, DeviceImage& img) {
     s.flags = (o.smooth ? 1 : 0) | (o.tex ? 2 : 0);
     s.type = o.type;
     s.orig = oi;
+  }
+
+  // the walk array: records in pre-order, links carry the target's leaf flag
+  {
+    std::vector<int64_t> unit_of((size_t)used + 1, 0);
+    for (int k = 0; k < used; k++)
+      unit_of[(size_t)k + 1] = unit_of[(size_t)k] + (sc.bvh[(size_t)order[(size_t)k]].end ? WALK_UNITS_LEAF : WALK_UNITS_INTERNAL);
+    if (unit_of[(size_t)used] >= ((int64_t)1 << 28)) { set_error("scene too large: the walk array must stay below 4 GiB (32-bit buffer offsets)"); return DR_ERR_SCENE; }
+    auto link_to = [&](int pre) -> int32_t {
+      if (pre < 0) return -1;
+      return (int32_t)((unit_of[(size_t)pre] << 1) | (sc.bvh[(size_t)order[(size_t)pre]].end ? 1 : 0));
+    };
+    img.walk.assign((size_t)unit_of[(size_t)used], DevUnit());
+    for (int k = 0; k < used; k++) {
+      const dr_bvh_node& b = sc.bvh[(size_t)order[(size_t)k]];
+      DevUnit* u = &img.walk[(size_t)unit_of[(size_t)k]];
+      int32_t w0 = b.end ? slot_of[(size_t)order[(size_t)k]] : link_to(k + 1);
+      int32_t w1 = link_to(b.miss_node < 0 ? -1 : new_id[(size_t)b.miss_node]);
+      memcpy(u[0].f, b.min, 12); memcpy(&u[0].f[3], &w0, 4);
+      memcpy(u[1].f, b.max, 12); memcpy(&u[1].f[3], &w1, 4);
+      if (b.end) memcpy(u[2].f, &img.prims[(size_t)slot_of[(size_t)order[(size_t)k]]], sizeof(DevPrim));
+    }
   }
 
   img.tex.clear();

@@ -7,7 +7,7 @@
 namespace dr {
 
 struct DeviceImage {
-  std::vector<DevNode> nodes;      // 2N - 1, pre-order
+  std::vector<DevUnit> walk;       // 2(N-1) + 5N units: the threaded walk (device_layout.h)
   std::vector<DevPair> pairs;      // N - 1, pre-order among internal nodes; pair 0 = root's children
   std::vector<DevPrim> prims;      // N, leaf order
   std::vector<DevShade> shade;     // N, leaf order

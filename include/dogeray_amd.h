@@ -151,7 +151,8 @@ int dr_accum_device_ptr(dr_context* c, void** dev_ptr, uint64_t* bytes);
 
 /* Counters and timings since the last dr_stats_reset.  Ray = one hit() call (K:800). */
 typedef struct dr_stats {
-  uint64_t frames;        /* kernel launches                                            */
+  uint64_t frames;        /* frames rendered                                            */
+  uint64_t launches;      /* render kernel launches (one launch may cover a batch of frames) */
   uint64_t samples;       /* primary samples                                            */
   uint64_t rays;          /* closest-hit queries (counted only when counters are on)    */
   uint64_t node_visits;   /* V: AABB tests performed by the kernel's traversal          */
@@ -161,6 +162,7 @@ typedef struct dr_stats {
   double kernel_ms;       /* sum of HIP-event durations of the render kernel launches   */
   uint64_t trav_slots;    /* 64 x wave-level traversal iterations: node_visits / trav_slots = SIMD efficiency of the node loop */
   uint64_t ray_slots;     /* 64 x wave-level closest-hit calls:    rays / ray_slots = SIMD efficiency of the bounce loop       */
+  uint64_t diag[4];       /* counting build of the persistent kernel: wave cycles, cycles in the shade phase, loop iterations, shade phases */
 } dr_stats;
 int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the kernel; off by default */
 int dr_stats_reset(dr_context* c);

@@ -782,7 +782,8 @@ struct RenderArgs {    // settings[13] K:2581 + W,H + backgroundintensity + fram
 };
 
 // Kernel K:998-1093 for one pixel
-void pixel(const Scene& s, const RenderArgs& a, int x, int y, unsigned stride, int32_t* out, Counters& c) {
+void pixel(const Scene& s, const RenderArgs& a, int x, int y, unsigned stride, int32_t* out, Counters& c, uint32_t* visits = nullptr) {
+  const uint64_t v_before = c.V;
   const float* st = a.settings;
   int W = a.W, H = a.H;
   size_t w = (size_t)x * H + y;                    // K:1006
@@ -817,6 +818,7 @@ void pixel(const Scene& s, const RenderArgs& a, int x, int y, unsigned stride, i
   out[3*w]   = f2i(color.x * 255 * scale);
   out[3*w+1] = f2i(color.y * 255 * scale);
   out[3*w+2] = f2i(color.z * 255 * scale);
+  if (visits) visits[w] = (uint32_t)(c.V - v_before);   // node visits spent on this pixel (load-balance studies)
 }
 
 }  // namespace
@@ -906,8 +908,8 @@ void orc_get_bvh(void* h, int32_t* active, int32_t* child0, int32_t* child1, int
 // One CudaStarter call (K:2562-2669) on the CPU.  out = int32[W*H*3], index (x*H + y)*3.
 // Pixels are rendered for block columns bx with bx % col_mod == col_rem (col_mod = 1 -> all);
 // everything else in `out` is zero (C9).  nthreads splits the block columns over std::threads.
-int orc_render(void* h, const float* settings13, int W, int H, float bgint, uint64_t frame_seed,
-               int32_t* out, OrcCounters* counters, int nthreads, int col_mod, int col_rem) {
+static int render_impl(void* h, const float* settings13, int W, int H, float bgint, uint64_t frame_seed,
+                       int32_t* out, OrcCounters* counters, int nthreads, int col_mod, int col_rem, uint32_t* visits) {
   Scene* s = (Scene*)h;
   if (s->bvh.empty()) { g_err = "BVH not built"; return -1; }
   RenderArgs a; memcpy(a.settings, settings13, sizeof(a.settings));
@@ -932,7 +934,7 @@ int orc_render(void* h, const float* settings13, int W, int H, float bgint, uint
       for (int by = 0; by < gy; by++)
         for (int tx = 0; tx < 8; tx++)
           for (int ty = 0; ty < 8; ty++)
-            pixel(*s, a, bx * 8 + tx, by * 8 + ty, stride, out, c);
+            pixel(*s, a, bx * 8 + tx, by * 8 + ty, stride, out, c, visits);
     }
     cs[(size_t)tid] = c;
   };
@@ -945,6 +947,16 @@ int orc_render(void* h, const float* settings13, int W, int H, float bgint, uint
   Counters tot; for (auto& c : cs) tot.add(c);
   if (counters) { counters->rays = tot.rays; counters->V = tot.V; counters->L = tot.L; counters->S = tot.S; counters->T = tot.T; counters->samples = tot.samples; }
   return 0;
+}
+
+int orc_render(void* h, const float* settings13, int W, int H, float bgint, uint64_t frame_seed,
+               int32_t* out, OrcCounters* counters, int nthreads, int col_mod, int col_rem) {
+  return render_impl(h, settings13, W, H, bgint, frame_seed, out, counters, nthreads, col_mod, col_rem, nullptr);
+}
+// same, and visits[x*H + y] = BVH node visits spent on that pixel (must be zero-filled by the caller)
+int orc_render_visits(void* h, const float* settings13, int W, int H, float bgint, uint64_t frame_seed,
+                      int32_t* out, OrcCounters* counters, int nthreads, int col_mod, int col_rem, uint32_t* visits) {
+  return render_impl(h, settings13, W, H, bgint, frame_seed, out, counters, nthreads, col_mod, col_rem, visits);
 }
 
 // ---- known-answer entry points (per-function checks of the HIP device code) ----

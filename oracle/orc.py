@@ -75,6 +75,8 @@ def lib(variant=""):
     L.orc_render.argtypes = [vp, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_void_p,
                              C.POINTER(OrcCounters), C.c_int, C.c_int, C.c_int]
     L.orc_render.restype = C.c_int
+    L.orc_render_visits.argtypes = L.orc_render.argtypes + [C.c_void_p]
+    L.orc_render_visits.restype = C.c_int
     L.orc_kat_rng.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
     L.orc_kat_rng_u32.argtypes = [C.c_uint64, C.c_int, C.c_void_p]
     L.orc_kat_aabb.argtypes = [C.c_int] + [C.c_void_p] * 6
@@ -158,6 +160,18 @@ class Scene:
         if rc != 0:
             raise RuntimeError(self.L.orc_last_error().decode())
         return out, c.as_dict()
+
+    def render_visits(self, settings13, W, H, bgint, frame_seed, nthreads=1, col_mod=1, col_rem=0):
+        """render() plus uint32[W, H] node visits per pixel."""
+        st = _f32(settings13)
+        out = np.zeros((W, H, 3), dtype=np.int32)
+        vis = np.zeros((W, H), dtype=np.uint32)
+        c = OrcCounters()
+        rc = self.L.orc_render_visits(self.h, _p(st), W, H, float(bgint), int(frame_seed) & (2 ** 64 - 1), _p(out),
+                                      C.byref(c), nthreads, col_mod, col_rem, _p(vis))
+        if rc != 0:
+            raise RuntimeError(self.L.orc_last_error().decode())
+        return out, c.as_dict(), vis
 
     def kat_hit(self, o, d):
         o, d = _f32(o), _f32(d)

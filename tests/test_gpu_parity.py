@@ -261,3 +261,25 @@ def test_stripes_partition_the_frame(dr, ctx, synth):
             total += part
         assert np.array_equal(total, full), R
     ctx.set_stripe(1, 0)
+
+
+def test_batched_accumulation_equals_frame_sum(dr, ctx, synth):
+    """dr_render_accumulate(nframes) may render several frames per launch (one work queue, atomic adds):
+    the accumulator must equal the sum of the frames rendered one at a time."""
+    ps = dr.Scene.load(os.path.join(synth["dir"], "hf_small.rts"))
+    ps.build_bvh()
+    ctx.upload(ps)
+    s = ps.settings()
+    st = dr.pack_settings13(s, 1)
+    W, H, n = 320, 192, 11
+    total = np.zeros((W, H, 3), dtype=np.int64)
+    for k in range(n):
+        total += ctx.render_frame(st, W, H, s.background, 5 + 1000003 * k)
+    ctx.accum_reset(W, H)
+    ctx.render_accumulate(st, W, H, s.background, 5, 1000003, n)
+    assert np.array_equal(ctx.accum_read().astype(np.int64), total)
+    # and again on top (accumulator keeps its contents)
+    ctx.render_accumulate(st, W, H, s.background, 5 + 1000003 * n, 1000003, 3)
+    for k in range(n, n + 3):
+        total += ctx.render_frame(st, W, H, s.background, 5 + 1000003 * k)
+    assert np.array_equal(ctx.accum_read().astype(np.int64), total)

@@ -1,0 +1,16 @@
+#!/bin/bash
+# A/B kernel variants on the GPU box: tools/ab.sh "4 6 8" [bench args]
+VARS=$1; shift
+mkdir -p gpurun_out
+for v in $VARS; do
+  DOGERAY_VARIANT=$v python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
+  python3 - <<PY
+import json
+j=json.loads(open("gpurun_out/ab_$v.json").read().strip().splitlines()[-1])
+print("variant $v: %.1f Mrays/s  kernel %.3f ms  frac %.3f  eff node %.3f bounce %.3f" % (j["value"], j["kernel_ms_per_frame"], j["roofline"]["frac"], j["simd_efficiency"]["node_loop"], j["simd_efficiency"]["bounce_loop"]))
+d=j.get("diag")
+if d and d[2]:
+    fr=j["steps"]
+    print("   diag/frame: wave-cycles %.3g  phase-cycles %.3g (%.1f%%)  iters %.3g  phases %.3g  cycles/iter %.0f  cycles/phase %.0f" % (d[0]/fr, d[1]/fr, 100.0*d[1]/max(1,d[0]), d[2]/fr, d[3]/fr, (d[0]-d[1])/max(1,d[2]), d[1]/max(1,d[3])))
+PY
+done
