@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 //
 // lane states (kept in `tr.node`): >= 0 walking; -1 walk finished, needs shading; -2 needs a new
 // sample or pixel; -3 retired.
-template <bool COUNT, int OCC, int TRAV_MIN>
+template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN>
 __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, unsigned* __restrict__ pixel_cost) {
   const int lane = threadIdx.x & 63;
@@ -99,14 +99,15 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   // diagnostic stamps (counting build only): wave lifetime, cycles inside the shade/refill phase
   unsigned long long t_begin = 0, t_phase = 0, n_iter = 0, n_phase = 0;
   if (COUNT) t_begin = __builtin_readcyclecounter();
+  ParkedLeaf pk; pk.P0 = pk.P1 = pk.P2 = make_float4(0, 0, 0, 0); pk.slot = 0; pk.parked = false;   // PARK_MIN > 0 only
   for (;;) {
-    const unsigned long long walking = __ballot(tr.node >= 0);
+    const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;
     if (__popcll(walking) < TRAV_MIN) {
       unsigned long long t0 = 0;
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
       // ---- shade the lanes whose walk has finished
-      if (tr.node == -1) {
+      if (tr.node == -1 && !(PARK_MIN > 0 && pk.parked)) {
         bool ended;
         V3 radiance = mk(0, 0, 0);
         if (tr.best_slot >= 0 && tr.best_t > 0.0f) {
@@ -193,11 +194,26 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
       if (__ballot(tr.node != -3) == 0ull) break;
     }
-    // ---- one node step for every walking lane
-    if (tr.node >= 0) {
-      if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
-      trav_step<COUNT>(walk, path.rayo, path.raydir, inv, tr, c);
-      steps++;
+    if (PARK_MIN > 0) {
+      // ---- test the parked leaves once enough lanes hold one (or nobody could step anyway)
+      const unsigned long long parked = __ballot(pk.parked);
+      const unsigned long long steppers = __ballot(tr.node >= 0 && !pk.parked);
+      if (parked != 0ull && (__popcll(parked) >= PARK_MIN || steppers == 0ull)) {
+        if (pk.parked) parked_test<COUNT>(path.rayo, path.raydir, tr, pk, c);
+      }
+      // ---- one node step for every lane that is walking and not parked
+      if (tr.node >= 0 && !pk.parked) {
+        if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
+        trav_step_park<COUNT>(walk, path.rayo, inv, tr, pk, c);
+        steps++;
+      }
+    } else {
+      // ---- one node step for every walking lane
+      if (tr.node >= 0) {
+        if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
+        trav_step<COUNT>(walk, path.rayo, path.raydir, inv, tr, c);
+        steps++;
+      }
     }
   }
   if (COUNT && lane == 0) {
@@ -354,9 +370,13 @@ struct dr_context {
   int stripe_mod = 1, stripe_rem = 0;
   int traversal = DR_TRAVERSAL_THREADED;
   bool count = false;
-  int variant = 4;          // kernel build variant (DOGERAY_VARIANT, tuning experiments)
+  // tunables (dr_context_set_option / DOGERAY_OPTIONS)
+  int kernel = DR_KERNEL_PERSISTENT;
+  int occupancy = 4;        // waves per SIMD the kernel is built and launched for
+  int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
+  int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
+  int batch_frames = 8;     // persistent kernel: frames per launch in dr_render_accumulate
   float cur_settings[13] = {0};
-  int batch_frames = 8;     // frames per launch of the persistent kernel in dr_render_accumulate (DOGERAY_BATCH)
   dr_stats stats;
 };
 
@@ -451,9 +471,14 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   return DR_OK;
 }
 
+constexpr int TILE_COUNTERS = 1024;
+
+inline bool uses_persistent(const dr_context* c) { return c->kernel == DR_KERNEL_PERSISTENT && c->traversal == DR_TRAVERSAL_THREADED; }
+
 template <int OCC>
-void launch_variant(dr_context* c, const RenderParams& P, dim3 grid) {
-  dim3 block(256);
+void launch_tile(dr_context* c, const RenderParams& P) {
+  const int tiles = P.ncols * P.gy;
+  dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
   const bool ordered = c->traversal == DR_TRAVERSAL_ORDERED;
   if (c->count) {
     if (ordered) hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_ORDERED, OCC>), grid, block, 0, c->stream, P);
@@ -464,83 +489,88 @@ void launch_variant(dr_context* c, const RenderParams& P, dim3 grid) {
   }
 }
 
-constexpr int TILE_COUNTERS = 1024;
-
-template <int OCC, int TRAV_MIN>
+template <int OCC, int TRAV_MIN, int PARK_MIN>
 void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pixel_cost) {
   int work = P.ncols * P.gy * P.batch;
   int blocks = c->num_cus * OCC;                   // OCC waves per SIMD on every CU
   if (blocks * 4 > work) blocks = (work + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
-  if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
-  else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
+  if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
+  else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
 }
 
-// Is the stored tile order for this view?  (Same settings, size and stripe: progressive frames.)
-bool order_matches(dr_context* c, const RenderParams& P, const float* key) {
-  return c->order_valid && memcmp(c->order_key, key, sizeof(c->order_key)) == 0;
+// The instantiated tunings; dr_context_set_option only accepts these values.
+template <int OCC>
+void launch_persistent_occ(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pcost) {
+  const int key = c->trav_min * 100 + c->park_min;
+  switch (key) {
+    case 3200: launch_persistent<OCC, 32, 0>(c, P, counter, order, pcost); break;
+    case 4800: launch_persistent<OCC, 48, 0>(c, P, counter, order, pcost); break;
+    case 4808: launch_persistent<OCC, 48, 8>(c, P, counter, order, pcost); break;
+    case 3216: launch_persistent<OCC, 32, 16>(c, P, counter, order, pcost); break;
+    default:   launch_persistent<OCC, 32, 8>(c, P, counter, order, pcost); break;
+  }
 }
 
-// enqueue one frame (no events, no sync)
+// Cost-feedback buffers for `tiles` tiles; returns the order to use for this launch (or null)
+// and the per-pixel cost buffer to fill (or null).
+void feedback_buffers(dr_context* c, const RenderParams& P, int tiles, const int*& order, unsigned*& pcost) {
+  order = nullptr; pcost = nullptr;
+  if (!c->feedback) return;
+  if (c->order_capacity < tiles) {
+    for (void* b : {(void*)c->pixel_cost, (void*)c->tile_cost, (void*)c->tile_order}) if (b) (void)hipFree(b);
+    c->pixel_cost = nullptr; c->tile_cost = nullptr; c->tile_order = nullptr; c->order_capacity = 0; c->order_valid = false;
+    if (hipMalloc((void**)&c->pixel_cost, (size_t)tiles * 64 * sizeof(unsigned)) == hipSuccess &&
+        hipMalloc((void**)&c->tile_cost, (size_t)tiles * sizeof(unsigned)) == hipSuccess &&
+        hipMalloc((void**)&c->tile_order, (size_t)tiles * sizeof(int)) == hipSuccess)
+      c->order_capacity = tiles;
+    else return;
+  }
+  // the stored order belongs to one view: same settings, size and stripe (progressive frames)
+  float key[16] = {0};
+  memcpy(key, c->cur_settings, 13 * sizeof(float));
+  key[13] = (float)P.W; key[14] = (float)P.H; key[15] = (float)(P.stripe_mod * 1024 + P.stripe_rem);
+  if (c->order_valid && memcmp(c->order_key, key, sizeof(key)) == 0) order = c->tile_order;
+  else { memcpy(c->order_key, key, sizeof(key)); c->order_valid = false; }
+  pcost = c->pixel_cost;
+}
+
+// enqueue one launch (P.batch frames); no events, no sync
 void enqueue_frame(dr_context* c, const RenderParams& P) {
-  int tiles = P.ncols * P.gy;
-  if (c->variant >= 1000 && c->traversal == DR_TRAVERSAL_THREADED) {
-    // persistent kernel: 1OTT = OCC O (4, 6, 8), TRAV_MIN TT
+  const int tiles = P.ncols * P.gy;
+  if (uses_persistent(c)) {
     if (c->tile_cursor >= TILE_COUNTERS) {
       (void)hipMemsetAsync(c->tile_counters, 0, TILE_COUNTERS * sizeof(unsigned), c->stream);
       c->tile_cursor = 0;
     }
     unsigned* counter = c->tile_counters + c->tile_cursor++;
-    // cost feedback buffers
-    const int* order = nullptr;
-    unsigned* pcost = nullptr;
-    if (c->feedback) {
-      if (c->order_capacity < tiles) {
-        for (void* b : {(void*)c->pixel_cost, (void*)c->tile_cost, (void*)c->tile_order}) if (b) (void)hipFree(b);
-        c->pixel_cost = nullptr; c->tile_cost = nullptr; c->tile_order = nullptr; c->order_capacity = 0; c->order_valid = false;
-        if (hipMalloc((void**)&c->pixel_cost, (size_t)tiles * 64 * sizeof(unsigned)) == hipSuccess &&
-            hipMalloc((void**)&c->tile_cost, (size_t)tiles * sizeof(unsigned)) == hipSuccess &&
-            hipMalloc((void**)&c->tile_order, (size_t)tiles * sizeof(int)) == hipSuccess)
-          c->order_capacity = tiles;
-      }
-      if (c->order_capacity >= tiles) {
-        float key[16] = {0};
-        memcpy(key, c->cur_settings, 13 * sizeof(float));
-        key[13] = (float)P.W; key[14] = (float)P.H; key[15] = (float)(P.stripe_mod * 1024 + P.stripe_rem);
-        if (order_matches(c, P, key)) order = c->tile_order;
-        else { memcpy(c->order_key, key, sizeof(key)); c->order_valid = false; }
-        pcost = c->pixel_cost;
-      }
-    }
-#define DR_LAUNCH_P(O, T) launch_persistent<O, T>(c, P, counter, order, pcost)
-    switch (c->variant) {
-      case 1432: DR_LAUNCH_P(4, 32); break;
-      case 1448: DR_LAUNCH_P(4, 48); break;
-      case 1464: DR_LAUNCH_P(4, 64); break;
-      case 1632: DR_LAUNCH_P(6, 32); break;
-      case 1648: DR_LAUNCH_P(6, 48); break;
-      case 1656: DR_LAUNCH_P(6, 56); break;
-      case 1664: DR_LAUNCH_P(6, 64); break;
-      case 1832: DR_LAUNCH_P(8, 32); break;
-      case 1848: DR_LAUNCH_P(8, 48); break;
-      case 1856: DR_LAUNCH_P(8, 56); break;
-      case 1864: DR_LAUNCH_P(8, 64); break;
-      default: DR_LAUNCH_P(6, 48); break;
-    }
-#undef DR_LAUNCH_P
-    if (pcost) {   // next frame's order from this frame's costs (stream-ordered, no host sync)
+    const int* order; unsigned* pcost;
+    feedback_buffers(c, P, tiles, order, pcost);
+    if (c->occupancy == 5) launch_persistent_occ<5>(c, P, counter, order, pcost);
+    else launch_persistent_occ<4>(c, P, counter, order, pcost);
+    if (pcost) {   // next launch's order from this launch's costs (stream-ordered, no host sync)
       hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);
       hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, tiles);
       c->order_valid = true;
     }
     return;
   }
-  dim3 grid((unsigned)((tiles + 3) / 4));
-  switch (c->variant) {
-    case 6: launch_variant<6>(c, P, grid); break;
-    case 8: launch_variant<8>(c, P, grid); break;
-    default: launch_variant<4>(c, P, grid); break;
-  }
+  if (c->occupancy >= 6) launch_tile<6>(c, P);
+  else launch_tile<4>(c, P);
+}
+
+int set_option(dr_context* c, const std::string& name, int v) {
+  if (name == "kernel") { if (v != DR_KERNEL_TILE && v != DR_KERNEL_PERSISTENT) goto bad; c->kernel = v; }
+  else if (name == "occupancy") { if (v != 4 && v != 5 && v != 6) goto bad; c->occupancy = v; }
+  else if (name == "trav_min") { if (v != 32 && v != 48) goto bad; c->trav_min = v; }
+  else if (name == "park_min") { if (v != 0 && v != 8 && v != 16) goto bad; c->park_min = v; }
+  else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
+  else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
+  else { set_error("unknown option '" + name + "'"); return DR_ERR_INVALID; }
+  return DR_OK;
+bad:
+  set_error("value not supported for option '" + name + "'");
+  return DR_ERR_INVALID;
 }
 
 int launch_render(dr_context* c, const RenderParams& P) {
@@ -591,9 +621,21 @@ int dr_context_create(int device_ordinal, dr_context** out) {
   HIP_TRY(hipSetDevice(device_ordinal));
   dr_context* c = new dr_context();
   c->device = device_ordinal;
-  if (const char* v = getenv("DOGERAY_VARIANT")) c->variant = atoi(v);
-  if (const char* v = getenv("DOGERAY_FEEDBACK")) c->feedback = atoi(v) != 0;
-  if (const char* v = getenv("DOGERAY_BATCH")) c->batch_frames = atoi(v) > 0 ? atoi(v) : 1;
+  if (const char* env = getenv("DOGERAY_OPTIONS")) {   // "name=value,name=value": tuning experiments without recompiling callers
+    std::string e(env);
+    size_t pos = 0;
+    while (pos < e.size()) {
+      size_t comma = e.find(',', pos);
+      if (comma == std::string::npos) comma = e.size();
+      std::string kv = e.substr(pos, comma - pos);
+      size_t eq = kv.find('=');
+      if (eq != std::string::npos && set_option(c, kv.substr(0, eq), atoi(kv.c_str() + eq + 1)) != DR_OK) {
+        delete c;
+        return DR_ERR_INVALID;
+      }
+      pos = comma + 1;
+    }
+  }
   {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
@@ -654,6 +696,11 @@ int dr_context_set_stripe(dr_context* c, int mod, int rem) {
   if (!c || mod < 1 || rem < 0 || rem >= mod) { set_error("stripe: need mod >= 1 and 0 <= rem < mod"); return DR_ERR_INVALID; }
   c->stripe_mod = mod; c->stripe_rem = rem;
   return DR_OK;
+}
+
+int dr_context_set_option(dr_context* c, const char* name, int value) {
+  if (!c || !name) { set_error("null argument"); return DR_ERR_INVALID; }
+  return set_option(c, name, value);
 }
 
 int dr_context_set_traversal(dr_context* c, int mode) {
@@ -719,7 +766,7 @@ int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H
   HIP_TRY(hipEventRecord(c->ev0, c->stream));
   // The persistent kernel renders the frames in batches of `batch_frames` per launch (one work
   // queue over all their tiles, atomic accumulation); the per-tile kernel takes one frame per launch.
-  const int per_launch = (c->variant >= 1000 && c->traversal == DR_TRAVERSAL_THREADED && c->batch_frames > 1) ? c->batch_frames : 1;
+  const int per_launch = (uses_persistent(c) && c->batch_frames > 1) ? c->batch_frames : 1;
   uint64_t launches = 0;
   for (int k = 0; k < nframes; k += per_launch) {
     P.seed = frame_seed + (uint64_t)k * seed_stride;

@@ -215,6 +215,43 @@ __device__ __forceinline__ void trav_step(WalkRsrc walk, V3 o, V3 d, V3 inv, Tra
   }
 }
 
+// Same step, but a leaf whose box passes is not tested on the spot: the lane keeps the primitive
+// record it has just fetched and waits ("parks") until enough lanes of the wave have one, so the
+// ~90-instruction triangle test runs once for many lanes instead of on nearly every iteration for
+// one or two.  The per-lane sequence of tests and updates is unchanged.
+struct ParkedLeaf { float4 P0, P1, P2; int slot; bool parked; };
+
+template <bool COUNT>
+__device__ __forceinline__ void trav_step_park(WalkRsrc walk, V3 o, V3 inv, Trav& tr, ParkedLeaf& pk, Ctr& c) {
+  const bool leaf = tr.node & 1;
+  const unsigned off = (unsigned)(tr.node >> 1) << 4;
+  float4 A = ld_unit(walk, off), B = ld_unit(walk, off + 16);
+  float4 P0 = A, P1 = A, P2 = A;
+  if (leaf) { P0 = ld_unit(walk, off + 32); P1 = ld_unit(walk, off + 48); P2 = ld_unit(walk, off + 64); }
+  float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
+  const int w0 = __float_as_int(A.w), miss = __float_as_int(B.w);
+  float dist;
+  if (COUNT) c.V++;
+  bool h = slab(o, inv, mn, mx, dist);
+  if (h && dist < tr.best_t) {
+    if (leaf) {
+      pk.P0 = P0; pk.P1 = P1; pk.P2 = P2; pk.slot = w0; pk.parked = true;
+      tr.node = miss;
+    } else {
+      tr.node = w0;
+    }
+  } else {
+    tr.node = miss;
+  }
+}
+template <bool COUNT>
+__device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk, Ctr& c) {
+  if (COUNT) c.L++;
+  float t = prim_hit_regs(pk.P0, pk.P1, pk.P2, o, d);
+  if (t > -0.01f && t < tr.best_t) { tr.best_t = t; tr.best_slot = pk.slot; }   // K:488
+  pk.parked = false;
+}
+
 __device__ __forceinline__ bool first_active_lane() { return __lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u; }
 
 template <bool COUNT>

@@ -128,6 +128,17 @@ int dr_context_set_stripe(dr_context* c, int mod, int rem);
 enum { DR_TRAVERSAL_THREADED = 0, DR_TRAVERSAL_ORDERED = 1 };
 int dr_context_set_traversal(dr_context* c, int mode);
 
+/* Tuning knobs of the render kernels; none of them changes a pixel.
+ *   "kernel"        DR_KERNEL_PERSISTENT (default): waves are pools of 64 path slots that refill
+ *                   from a tile queue; DR_KERNEL_TILE: one wave per 8x8 tile, the reference's launch shape
+ *   "batch_frames"  frames rendered per launch by dr_render_accumulate (persistent kernel), default 8
+ *   "feedback"      1 (default): tiles are started most-expensive-first using the previous launch's costs
+ *   "occupancy"     waves per SIMD (4 or 5; 6 for the tile kernel)
+ *   "trav_min"      32 or 48;  "park_min"  0, 8 or 16   (persistent kernel scheduling thresholds)
+ * The environment variable DOGERAY_OPTIONS="name=value,..." applies the same at context creation. */
+enum { DR_KERNEL_TILE = 0, DR_KERNEL_PERSISTENT = 1 };
+int dr_context_set_option(dr_context* c, const char* name, int value);
+
 /* One CudaStarter call.  settings13 = { cam.xyz, look.xyz, aperture, focus, fov, max_depth,
  * spp, divisor, backtex } exactly as packed at K:2581; W,H = SCREEN_WIDTH/HEIGHT;
  * background = backgroundintensity[0] (K:108,2103); frame_seed replaces clock() at K:1065.

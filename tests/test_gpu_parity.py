@@ -142,10 +142,11 @@ def test_closest_hit_queries(dr, orc, ctx, synth, mode):
     ctx.set_traversal(0)
 
 
-def _render_pair(dr, orc, ctx, path, texdir, W, H, div, seed, spp=None, depth=None, mode=0):
+def _render_pair(dr, orc, ctx, path, texdir, W, H, div, seed, spp=None, depth=None, mode=0, kernel=1):
     ps, os_ = _load_both(dr, orc, path, texdir)
     ctx.upload(ps)
     ctx.set_traversal(mode)
+    ctx.set_option("kernel", kernel)      # 0: one wave per tile, 1: persistent (ordered traversal always runs the tile kernel)
     s = ps.settings()
     so = os_.settings()
     assert bytes(s) == bytes(so)
@@ -159,6 +160,7 @@ def _render_pair(dr, orc, ctx, path, texdir, W, H, div, seed, spp=None, depth=No
     assert np.array_equal(g, g2), "counting and non-counting kernels disagree"
     r, rc = os_.render(st, W, H, s.background, seed, nthreads=4)
     ctx.set_traversal(0)
+    ctx.set_option("kernel", 1)
     return g, r, stats, rc
 
 
@@ -168,21 +170,22 @@ def _assert_frames(g, r, what):
     assert frac == 1.0, "%s: only %.6f of pixels identical (max diff %d)" % (what, frac, maxdiff)
 
 
-def test_cube_ladder_frames(dr, orc, ctx, tmp_path):
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_cube_ladder_frames(dr, orc, ctx, tmp_path, kernel):
     """Config C1: samples/cube.rts 256x256 1 spp, every preview-ladder stage (K:2169-2211)."""
     path = with_settings(os.path.join(SCENES, "cube.rts"), str(tmp_path / "cube256.rts"), CUBE_SETTINGS)
     for k, (div, spp, depth) in enumerate([(8, None, None), (4, 1, 2), (2, 1, 2), (1, 1, 2), (1, None, None), (1, None, None)]):
         seed = 1 + 1000003 * k
-        g, r, stats, rc = _render_pair(dr, orc, ctx, path, "", 256, 256, div, seed, spp, depth)
-        _assert_frames(g, r, "cube stage %d" % k)
+        g, r, stats, rc = _render_pair(dr, orc, ctx, path, "", 256, 256, div, seed, spp, depth, kernel=kernel)
+        _assert_frames(g, r, "cube stage %d kernel %d" % (k, kernel))
         if div > 1:   # unrendered margin is 0
             assert not g[256 // div:, :, :].any() and not g[:, 256 // div:, :].any()
         for a, b in (("rays", "rays"), ("node_visits", "V"), ("prim_tests", "L"), ("shades", "S"), ("texels", "T"), ("samples", "samples")):
             assert stats[a] == rc[b], (k, a, stats[a], rc[b])
 
 
-@pytest.mark.parametrize("mode", [0, 1])
-def test_scene_frames(dr, orc, ctx, synth, mode):
+@pytest.mark.parametrize("mode,kernel", [(0, 1), (0, 0), (1, 0)])
+def test_scene_frames(dr, orc, ctx, synth, mode, kernel):
     """Spheres, every material, textures, checker, env map, smooth normals, large meshes."""
     cases = [
         (os.path.join(SCENES, "scene.rts"), "", 320, 192),              # spheres + the unsupported type 1
@@ -196,8 +199,8 @@ def test_scene_frames(dr, orc, ctx, synth, mode):
     ]
     for path, tex, W, H in cases:
         for seed in (3, 1 + 1000003 * 7):
-            g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, 1, seed, mode=mode)
-            _assert_frames(g, r, "%s seed %d mode %d" % (os.path.basename(path), seed, mode))
+            g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, 1, seed, mode=mode, kernel=kernel)
+            _assert_frames(g, r, "%s seed %d traversal %d kernel %d" % (os.path.basename(path), seed, mode, kernel))
             assert stats["rays"] == rc["rays"] and stats["shades"] == rc["S"] and stats["texels"] == rc["T"]
             if mode == 0:
                 assert stats["node_visits"] == rc["V"] and stats["prim_tests"] == rc["L"]
@@ -205,12 +208,13 @@ def test_scene_frames(dr, orc, ctx, synth, mode):
                 print("   node visits: ordered %d vs reference order %d" % (stats["node_visits"], rc["V"]))
 
 
-def test_spp_and_aperture(dr, orc, ctx, synth, tmp_path):
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_spp_and_aperture(dr, orc, ctx, synth, tmp_path, kernel):
     """spp > 1 inside one launch (per-sample reseed, K:1059-1065) and a wide lens (K:1071-1073)."""
     src = os.path.join(synth["dir"], "matball.rts")
     path = with_settings(src, str(tmp_path / "mb4.rts"),
                          "*,0,-2.5,7,0.6,0,-0.5,0,7,50,6,4,0.9,synth_env.ppm,192,128")
-    g, r, stats, rc = _render_pair(dr, orc, ctx, path, synth["tex"], 192, 128, 1, 77)
+    g, r, stats, rc = _render_pair(dr, orc, ctx, path, synth["tex"], 192, 128, 1, 77, kernel=kernel)
     _assert_frames(g, r, "matball 4 spp")
     assert stats["samples"] == 192 * 128 * 4
 
@@ -283,3 +287,33 @@ def test_batched_accumulation_equals_frame_sum(dr, ctx, synth):
     for k in range(n, n + 3):
         total += ctx.render_frame(st, W, H, s.background, 5 + 1000003 * k)
     assert np.array_equal(ctx.accum_read().astype(np.int64), total)
+
+
+def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
+    """Every scheduling knob (kernel, occupancy, thresholds, batching, tile order) leaves the frame bit-identical."""
+    ps = dr.Scene.load(os.path.join(synth["dir"], "city_small.rts"))
+    ps.build_bvh()
+    ctx.upload(ps)
+    s = ps.settings()
+    st = dr.pack_settings13(s, 1)
+    W, H = 320, 192
+    base = None
+    combos = [{"kernel": 0, "occupancy": 4}, {"kernel": 0, "occupancy": 6}, {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 8},
+              {"kernel": 1, "occupancy": 5, "trav_min": 48, "park_min": 0}, {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 16},
+              {"kernel": 1, "occupancy": 4, "trav_min": 48, "park_min": 8, "feedback": 0}, {"kernel": 1, "batch_frames": 3}]
+    for opts in combos:
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        ctx.accum_reset(W, H)
+        ctx.render_accumulate(st, W, H, s.background, 21, 1000003, 7)
+        ctx.render_accumulate(st, W, H, s.background, 21 + 7 * 1000003, 1000003, 2)   # second call reuses the tile order
+        acc = ctx.accum_read()
+        if base is None:
+            base = acc
+        assert np.array_equal(acc, base), opts
+    for k, v in {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 8}.items():
+        ctx.set_option(k, v)
+    with pytest.raises(dr.DogerayError):
+        ctx.set_option("park_min", 7)
+    with pytest.raises(dr.DogerayError):
+        ctx.set_option("no_such_option", 1)

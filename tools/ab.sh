@@ -1,13 +1,13 @@
 #!/bin/bash
-# A/B kernel variants on the GPU box: tools/ab.sh "4 6 8" [bench args]
+# A/B option sets on the GPU box: tools/ab.sh "kernel=0 kernel=1,park_min=0" [bench args]
 VARS=$1; shift
 mkdir -p gpurun_out
 for v in $VARS; do
-  DOGERAY_VARIANT=$v python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
+  DOGERAY_OPTIONS=$v python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
   python3 - <<PY
 import json
 j=json.loads(open("gpurun_out/ab_$v.json").read().strip().splitlines()[-1])
-print("variant $v: %.1f Mrays/s  kernel %.3f ms  frac %.3f  eff node %.3f bounce %.3f" % (j["value"], j["kernel_ms_per_frame"], j["roofline"]["frac"], j["simd_efficiency"]["node_loop"], j["simd_efficiency"]["bounce_loop"]))
+print("options $v: %.1f Mrays/s  kernel %.3f ms  frac %.3f  eff node %.3f bounce %.3f" % (j["value"], j["kernel_ms_per_frame"], j["roofline"]["frac"], j["simd_efficiency"]["node_loop"], j["simd_efficiency"]["bounce_loop"]))
 d=j.get("diag")
 if d and d[2]:
     fr=j["steps"]
