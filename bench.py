@@ -120,6 +120,7 @@ def main():
             ctx.render_accumulate(st, W, H, s.background, seed_base + (first + k) * seed_stride, seed_stride, n)
             if world > 1:
                 multigpu.gather_frame(acc, W, H, world, rank)
+                torch.cuda.synchronize()      # the gather reads the accumulator on torch's stream: finish before the next frames write it
             k += n
 
     def fence():

@@ -317,3 +317,31 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         ctx.set_option("park_min", 7)
     with pytest.raises(dr.DogerayError):
         ctx.set_option("no_such_option", 1)
+
+
+def test_accumulator_tensor_aliases_device_memory(dr, ctx, synth):
+    """multigpu.accumulator_tensor wraps the library's accumulator for torch.distributed without a copy."""
+    import torch
+    from dogeray_amd import multigpu
+    ps = dr.Scene.load(os.path.join(synth["dir"], "city_small.rts"))
+    ps.build_bvh()
+    ctx.upload(ps)
+    s = ps.settings()
+    st = dr.pack_settings13(s, 1)
+    W, H = 320, 192
+    ctx.accum_reset(W, H)
+    ctx.render_accumulate(st, W, H, s.background, 3, 1, 2)
+    t = multigpu.accumulator_tensor(ctx, torch.device("cuda", 0))
+    assert t.dtype == torch.int32 and t.numel() == W * H * 3
+    host = ctx.accum_read()
+    assert np.array_equal(t.cpu().numpy().reshape(W, H, 3), host)
+    ctx.render_accumulate(st, W, H, s.background, 5, 1, 1)                 # the tensor sees later frames: same memory
+    torch.cuda.synchronize()
+    assert np.array_equal(t.cpu().numpy().reshape(W, H, 3), ctx.accum_read())
+    assert multigpu.gather_frame(t, W, H, 1, 0) is t
+    # pack / unpack used by the gather, on the device: columns r::R of the [gx, 8*H*3] view
+    cols = t[: (W // 8) * 8 * H * 3].view(W // 8, 8 * H * 3)
+    back = torch.zeros_like(cols)
+    for r in range(3):
+        back[r::3] = cols[r::3].contiguous()
+    assert torch.equal(back, cols)

@@ -1,0 +1,212 @@
+"""CPU tests of the product's host side (C++ behind the C ABI): .rts reader, texture discovery,
+bit-exact BVH builder, error behaviour -- each against the oracle on the same files -- and the
+C ABI surface itself (every symbol of include/dogeray_amd.h is exported; no silent CPU fallback)."""
+import ctypes
+import glob
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, SCENES, SCENEGEN
+
+
+@pytest.fixture(scope="module")
+def dr():
+    import dogeray_amd
+    return dogeray_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import orc as o
+    return o
+
+
+SCENE_FILES = sorted(glob.glob(os.path.join(SCENES, "*.rts")))
+
+
+def assert_same_objects(ps, os_):
+    po, oo = ps.objects(), os_.objects()
+    assert po.dtype.itemsize == oo.dtype.itemsize == 168
+    assert po.tobytes() == oo.tobytes()
+    assert bytes(ps.settings()) == bytes(os_.settings())
+
+
+def assert_same_bvh(ps, os_):
+    ob = os_.build_bvh()
+    ps.build_bvh()
+    pb, used = ps.bvh()
+    assert used == ob["used"] and len(pb) == len(ob["hit"])
+    live = ob["active"] == 1
+    leaf = live & (ob["end"] == 1)
+    inner = live & (ob["end"] == 0)
+    assert np.array_equal(pb["active"], ob["active"])
+    for mine, theirs, mask in (("count", "count", live), ("end", "end", live), ("hit_node", "hit", live), ("miss_node", "miss", live),
+                               ("under", "under", leaf)):
+        assert np.array_equal(pb[mine][mask], ob[theirs][mask]), mine
+    assert np.array_equal(pb["children"][inner][:, 0], ob["child0"][inner])
+    assert np.array_equal(pb["children"][inner][:, 1], ob["child1"][inner])
+    assert pb["min"][live].tobytes() == ob["min"][live].tobytes()      # float bounds bit for bit
+    assert pb["max"][live].tobytes() == ob["max"][live].tobytes()
+
+
+@pytest.mark.parametrize("path", SCENE_FILES, ids=[os.path.basename(p) for p in SCENE_FILES])
+def test_reader_and_bvh_match_oracle_on_samples(dr, orc, synth, path):
+    """Every copied reference sample (13/16/19/28/36/37/38-column generations, partial lines,
+    spheres, texture names) parses and builds to the same bytes as the oracle."""
+    ps = dr.Scene.load(path, synth["tex"])
+    os_ = orc.Scene(path, synth["tex"])
+    assert ps.num_objects == os_.n
+    assert_same_objects(ps, os_)
+    if os_.n >= 2:
+        assert_same_bvh(ps, os_)
+
+
+def test_texture_discovery_and_name_resolution(dr, orc, synth):
+    ps = dr.Scene.load(os.path.join(SCENES, "cow.rts"), synth["tex"])
+    os_ = orc.Scene(os.path.join(SCENES, "cow.rts"), synth["tex"])
+    pt, ot = ps.textures(), os_.textures()
+    assert len(pt) == len(ot) == 7
+    for a, b in zip(pt, ot):
+        assert a.shape == b.shape and np.array_equal(a, b)
+        assert not a[..., 3].any()                       # sdkLoadPPM4: alpha = 0
+    objs = ps.objects()
+    assert set(np.unique(objs["texnum"][:-1])) == {0, 6}   # a.ppm and testtwo.ppm in sorted directory order
+    # capitals in the query never match the lower-cased path (K:1177-1178)
+    d = os.path.join(synth["dir"], "caps")
+    os.makedirs(d, exist_ok=True)
+    subprocess.check_call([SCENEGEN, "ppm", os.path.join(d, "Checker.ppm"), "8", "8", "0"])
+    p = os.path.join(synth["dir"], "caps.rts")
+    line = "0,0,0,2,1,1,1,0,0,1,0,0,0,0,1,0,0,0,1,0,0,1,0,0,1,0,0,1,0,0,1,0,0,1,0,0,%s,no\n"
+    open(p, "w").write(line % "Checker.ppm" + line % "checker.ppm")
+    for sc in (dr.Scene.load(p, d).objects(), orc.Scene(p, d).objects()):
+        assert list(sc["texnum"][:2]) == [-1, 0]
+    assert dr.Scene.load(p, "").objects()["texnum"][1] == -1   # "" = no texture directory
+
+
+def test_synthetic_scenes_match_oracle(dr, orc, synth):
+    for name in ("matball.rts", "hf_small.rts", "bunny_small.rts", "city_small.rts"):
+        path = os.path.join(synth["dir"], name)
+        ps, os_ = dr.Scene.load(path, synth["tex"]), orc.Scene(path, synth["tex"])
+        assert_same_objects(ps, os_)
+        assert_same_bvh(ps, os_)
+
+
+def test_bvh_thread_count_does_not_matter(dr, synth, tmp_path):
+    path = str(tmp_path / "hf.rts")
+    subprocess.check_call([SCENEGEN, "heightfield", path, "150", "320", "192"])   # 44 402 triangles: above the fan-out threshold
+    ps = dr.Scene.load(path)
+    ps.build_bvh(1)
+    a, _ = ps.bvh()
+    for t in (2, 3, 8, 0):
+        ps.build_bvh(t)
+        b, _ = ps.bvh()
+        assert a.tobytes() == b.tobytes(), t
+
+
+def test_reader_edge_cases(dr, orc, tmp_path):
+    tri = "1,2,3,2,0.5,0.5,0.5,0,0,1,1,1,0,2,2,2"
+    cases = {
+        "crlf.rts": tri + "\r\n" + tri + "\r\n",                          # '\r' stays in the last field; stof ignores it
+        "noeol.rts": tri + "\n" + tri,                                     # last line without newline
+        "comments.rts": "/a comment\n" + tri + "\n/another\n*,1,2,3,0.02,0,0,0,5,60.9,7.2,3\n" + tri + "\n",
+        "short.rts": "00\n.1\n" + tri + "\n",                              # partial lines keep the struct defaults
+        "spaces.rts": " 1, 2,3 ,2,0.5,0.5,0.5,0,0,1,1,1,0,2,2,2\n" + tri + "\n",   # stof skips leading blanks, ignores trailing ones
+        "extra.rts": tri + "," + ",".join(["0"] * 22) + ",no,no,99,junk\n" + tri + "\n",   # columns past 37 are never converted
+        "settings_all.rts": "*,1,2,3,0.02,4,5,6,7,50,9,2,0.5,no,640,360\n" + tri + "\n" + tri + "\n",
+    }
+    for name, text in cases.items():
+        p = tmp_path / name
+        p.write_bytes(text.encode())
+        ps, os_ = dr.Scene.load(str(p)), orc.Scene(str(p))
+        assert ps.num_objects == os_.n, name
+        assert_same_objects(ps, os_)
+    s = dr.Scene.load(str(tmp_path / "comments.rts")).settings()
+    assert (s.fov, s.max_depth, s.spp) == (60, 7, 3) and abs(s.aperture - 0.02) < 1e-9     # stoi("60.9") == 60
+    s = dr.Scene.load(str(tmp_path / "settings_all.rts")).settings()
+    assert (s.width, s.height, s.backtex) == (640, 360, -1)
+    d = dr.Scene.load(str(tmp_path / "short.rts")).objects()
+    assert d["norm"][0].tolist() == [-2, -3, -20] and d["texnum"][0] == -1 and d["t1"][0].tolist() == [0, 1, 0]   # K:55-71
+
+
+def test_error_behaviour(dr, tmp_path):
+    """Where the reference throws or recurses forever, the C ABI returns a negative status."""
+    tri = "1,2,3,2,0.5,0.5,0.5,0,0,1,1,1,0,2,2,2"
+    bad = {"empty_line.rts": tri + "\n\n" + tri + "\n", "trailing_comma.rts": tri + ",\n" + tri + "\n",
+           "letters.rts": "abc,2,3,2\n" + tri + "\n", "bad_int.rts": "1,2,3,x\n" + tri + "\n"}
+    for name, text in bad.items():
+        p = tmp_path / name
+        p.write_text(text)
+        with pytest.raises(dr.DogerayError) as e:
+            dr.Scene.load(str(p))
+        assert e.value.code == -3, name                       # DR_ERR_PARSE
+        assert "line" in str(e.value)
+    with pytest.raises(dr.DogerayError) as e:
+        dr.Scene.load(str(tmp_path / "nope.rts"))
+    assert e.value.code == -2                                 # DR_ERR_IO
+    with pytest.raises(dr.DogerayError) as e:
+        dr.Scene.load(str(tmp_path / "empty_line.rts"), str(tmp_path / "no_such_dir"))
+    assert e.value.code == -2
+    one = tmp_path / "one.rts"
+    one.write_text(tri + "\n")
+    s = dr.Scene.load(str(one))
+    with pytest.raises(dr.DogerayError) as e:
+        s.build_bvh()
+    assert e.value.code == -4                                 # DR_ERR_SCENE
+
+
+def test_random_field_is_reproducible(dr, tmp_path):
+    p = tmp_path / "r.rts"
+    p.write_text("r,r,r,2,r,0.5,0.5,0,0,1,1,1,0,2,2,2\n1,2,3,2,0.5,0.5,0.5,0,0,1,1,1,0,2,2,2\n")
+    a, b = dr.Scene.load(str(p)).objects(), dr.Scene.load(str(p)).objects()
+    assert a.tobytes() == b.tobytes()
+    assert 0 <= a["pos"][0][0] < 1 and a["pos"][0][0] != a["pos"][0][1]
+
+
+# ------------------------------------------------------------------------------ C ABI surface
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "dogeray_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(dr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(dr):
+    names = header_functions()
+    assert len(names) >= 35
+    L = ctypes.CDLL(os.path.join(ROOT, "dogeray_amd", "libdogeray_amd.so"))
+    for n in names:
+        assert hasattr(L, n), "libdogeray_amd.so does not export %s" % n
+    assert sorted(dr.API_SYMBOLS) == names, "python binding and header disagree"
+    assert dr.lib().dr_abi_version() == 1
+
+
+def test_struct_layouts_match_header(dr):
+    assert ctypes.sizeof(dr.DrObject) == 168 and dr.OBJECT_DTYPE.itemsize == 168
+    assert dr.BVH_DTYPE.itemsize == 56
+    assert ctypes.sizeof(dr.DrSettings) == 60
+
+
+def test_no_cpu_fallback(dr):
+    """Without a GPU the device entry points fail loudly; nothing renders on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert dr.device_count() == 0
+    with pytest.raises(dr.DogerayError) as e:
+        dr.Context(0)
+    assert e.value.code == -5 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+    """dogeray_amd/ must not import, link or open anything under oracle/."""
+    for root, _, files in os.walk(os.path.join(ROOT, "dogeray_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                text = open(os.path.join(root, f), errors="replace").read()
+                assert "liboracle" not in text and "dogeray_oracle" not in text, f
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
+    out = subprocess.run(["ldd", os.path.join(ROOT, "dogeray_amd", "libdogeray_amd.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out
