@@ -51,6 +51,15 @@ def build(force=False, verbose=False):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    # the headless host application: plain C++ over the C ABI only
+    exe = os.path.join(HERE, "bin", "dogeray")
+    main_src = os.path.join(CSRC, "dogeray_main.cpp")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    if force or _stale(exe, [main_src, LIB] + headers):
+        cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Wextra", main_src, "-o", exe, "-L" + HERE, "-ldogeray_amd", "-Wl,-rpath,$ORIGIN/.."]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return LIB
 
 

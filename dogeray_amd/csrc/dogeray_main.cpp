@@ -1,0 +1,177 @@
+// dogeray -- headless host application over the C ABI (include/dogeray_amd.h).
+//
+// Mirrors the reference's main() (kernel.cu K:2021-2557) without SDL2 (absent in this image):
+//   argv[1] or scene.rts                                   K:2041-2051
+//   getnum/read/readtextures/build_bvh                     K:2055-2094  -> dr_scene_load / dr_scene_build_bvh
+//   present loop: 1/8, 1/4, 1/2, 1/1 previews then full-res frames accumulated,
+//   display value clamp(sum / (iter - pnum), 0, 255)       K:2154-2322  -> dr_render_accumulate / dr_accum_present
+//   status line "Time = ..[us]  .. FPS  .. samples"        K:2327
+//   SPACE -> <scene>.bmp                                   K:2501-2516  -> --out FILE (.bmp or .ppm) at exit
+// Everything that touches the GPU goes through dr_* calls; this file includes no HIP header.
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dogeray_amd.h"
+
+namespace {
+
+void die(const char* what) {
+  fprintf(stderr, "dogeray: %s: %s\n", what, dr_last_error());
+  exit(1);
+}
+
+void pack13(const dr_settings& s, int divisor, int spp, int depth, float out[13]) {   // K:2581
+  const float v[13] = {s.campos[0], s.campos[1], s.campos[2], s.look[0], s.look[1], s.look[2], s.aperture, s.focus_dist,
+                       (float)s.fov, (float)depth, (float)spp, (float)divisor, (float)s.backtex};
+  memcpy(out, v, sizeof(v));
+}
+
+bool ends_with(const std::string& s, const char* suf) {
+  size_t n = strlen(suf);
+  return s.size() >= n && s.compare(s.size() - n, n, suf) == 0;
+}
+
+bool write_ppm(const std::string& path, const std::vector<uint8_t>& rgb, int W, int H) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  fprintf(f, "P6\n%d %d\n255\n", W, H);
+  bool ok = fwrite(rgb.data(), 1, rgb.size(), f) == rgb.size();
+  fclose(f);
+  return ok;
+}
+
+// 24-bit bottom-up BMP (the reference saves the window surface with SDL_SaveBMP, K:2505-2513)
+bool write_bmp(const std::string& path, const std::vector<uint8_t>& rgb, int W, int H) {
+  FILE* f = fopen(path.c_str(), "wb");
+  if (!f) return false;
+  const uint32_t row = ((uint32_t)W * 3 + 3) & ~3u, size = row * (uint32_t)H;
+  uint8_t hdr[54] = {'B', 'M'};
+  auto put32 = [&](int off, uint32_t v) { memcpy(hdr + off, &v, 4); };
+  auto put16 = [&](int off, uint16_t v) { memcpy(hdr + off, &v, 2); };
+  put32(2, 54 + size); put32(10, 54); put32(14, 40); put32(18, (uint32_t)W); put32(22, (uint32_t)H);
+  put16(26, 1); put16(28, 24); put32(34, size); put32(38, 2835); put32(42, 2835);
+  bool ok = fwrite(hdr, 1, sizeof(hdr), f) == sizeof(hdr);
+  std::vector<uint8_t> line(row, 0);
+  for (int y = H - 1; y >= 0 && ok; y--) {
+    const uint8_t* src = &rgb[(size_t)y * W * 3];
+    for (int x = 0; x < W; x++) { line[(size_t)x * 3] = src[(size_t)x * 3 + 2]; line[(size_t)x * 3 + 1] = src[(size_t)x * 3 + 1]; line[(size_t)x * 3 + 2] = src[(size_t)x * 3]; }
+    ok = fwrite(line.data(), 1, row, f) == row;
+  }
+  fclose(f);
+  return ok;
+}
+
+void usage() {
+  fprintf(stderr,
+          "usage: dogeray [scene.rts] [--textures DIR] [--frames N] [--out FILE.bmp|.ppm] [--width W] [--height H]\n"
+          "               [--spp S] [--depth D] [--seed N] [--device I] [--group G] [--quiet]\n"
+          "  scene        .rts file (default scene.rts, as the reference)\n"
+          "  --textures   directory scanned for *ppm* textures (default: current directory, as the reference)\n"
+          "  --frames     full-resolution frames to accumulate after the 4 preview stages (default 64)\n"
+          "  --group      frames rendered between two presents once accumulating (default 8)\n");
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  std::string scene_path = "scene.rts", out_path;
+  const char* texdir = nullptr;
+  int frames = 64, device = 0, group = 8, width = 0, height = 0, spp = 0, depth = 0;
+  uint64_t seed = 1;
+  bool quiet = false, have_scene = false;
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
+    if (a == "--textures") texdir = next();
+    else if (a == "--frames") frames = atoi(next());
+    else if (a == "--out") out_path = next();
+    else if (a == "--width") width = atoi(next());
+    else if (a == "--height") height = atoi(next());
+    else if (a == "--spp") spp = atoi(next());
+    else if (a == "--depth") depth = atoi(next());
+    else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
+    else if (a == "--device") device = atoi(next());
+    else if (a == "--group") group = atoi(next());
+    else if (a == "--quiet") quiet = true;
+    else if (a == "-h" || a == "--help") { usage(); return 0; }
+    else if (!have_scene && a[0] != '-') { scene_path = a; have_scene = true; }
+    else { usage(); return 2; }
+  }
+  if (group < 1) group = 1;
+
+  if (!quiet) printf("DOGERAY render path on MI355X (dogeray_amd, C ABI v%d)\n", dr_abi_version());
+  printf("%s%s\n", have_scene ? "Opening:" : "Opening Default Scene: ", scene_path.c_str());   // K:2045-2050
+  dr_scene* scene = nullptr;
+  if (dr_scene_load(scene_path.c_str(), texdir, &scene) != DR_OK) die("cannot load scene");
+  printf("%d tris\n%d textures total\n", dr_scene_num_objects(scene) + 1, dr_scene_num_textures(scene));   // K:2056,1995 (objnum = count + 1)
+  dr_settings s;
+  dr_scene_get_settings(scene, &s);
+  if (width > 0) s.width = width;
+  if (height > 0) s.height = height;
+  if (spp > 0) s.spp = spp;
+  if (depth > 0) s.max_depth = depth;
+  printf("Building BVH..\n");
+  auto t0 = std::chrono::steady_clock::now();
+  if (dr_scene_build_bvh(scene, 0) != DR_OK) die("cannot build the BVH");
+  double bvh_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  printf("Done!\n%d nodes total (%.0f ms)\n", dr_scene_bvh_size(scene), bvh_ms);               // K:2093-2094
+
+  dr_context* ctx = nullptr;
+  if (dr_context_create(device, &ctx) != DR_OK) die("cannot create the device context");
+  if (dr_context_upload_scene(ctx, scene) != DR_OK) die("cannot upload the scene");
+  const int W = s.width, H = s.height;
+  if (dr_accum_reset(ctx, W, H) != DR_OK) die("cannot allocate the accumulator");
+
+  // ---- the present loop (K:2154-2224)
+  int iter = 0;
+  uint64_t frame_no = 0;
+  const uint64_t seed_stride = 1000003;
+  std::vector<uint8_t> rgb((size_t)W * H * 3);
+  int divide_by = 1;
+  const int total_iters = 4 + frames;
+  while (iter < total_iters) {
+    auto begin = std::chrono::steady_clock::now();
+    float st[13];
+    int pnum, n = 1;
+    if (iter < 4) {
+      static const int ladder[4] = {8, 4, 2, 1};
+      // iter 0 runs with the file's spp/depth, iters 1-3 with spp 1 / depth 2 (K:2171-2204)
+      pack13(s, ladder[iter], iter == 0 ? s.spp : 1, iter == 0 ? s.max_depth : 2, st);
+      if (dr_accum_reset(ctx, W, H) != DR_OK) die("reset");          // CudaStarter overwrites outr on these calls
+      pnum = iter;
+    } else {
+      pack13(s, 1, s.spp, s.max_depth, st);
+      n = total_iters - iter < group ? total_iters - iter : group;   // several frames per present
+      pnum = 3;
+    }
+    if (dr_render_accumulate(ctx, st, W, H, s.background, seed + frame_no * seed_stride, seed_stride, n) != DR_OK) die("render");
+    frame_no += (uint64_t)n;
+    iter += n;
+    divide_by = iter - pnum;                                          // K:2287
+    if (dr_accum_present(ctx, divide_by, rgb.data()) != DR_OK) die("present");
+    long long us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - begin).count();
+    if (!quiet) {
+      printf("\rTime = %lld[us]  %.2f FPS       %d samples             ", us, us > 0 ? 1e6 * n / (double)us : 0.0, divide_by * s.spp);   // K:2327
+      fflush(stdout);
+    }
+  }
+  if (!quiet) printf("\n");
+
+  dr_stats stats;
+  if (dr_stats_get(ctx, &stats) == DR_OK && stats.frames > 0)
+    printf("rendered %llu frames in %llu launches, %.3f ms of kernel time per frame\n", (unsigned long long)stats.frames,
+           (unsigned long long)stats.launches, stats.kernel_ms / (double)stats.frames);
+  if (!out_path.empty()) {
+    bool ok = ends_with(out_path, ".ppm") ? write_ppm(out_path, rgb, W, H) : write_bmp(out_path, rgb, W, H);
+    if (!ok) { fprintf(stderr, "dogeray: cannot write %s\n", out_path.c_str()); return 1; }
+    printf("exported image:%s\n", out_path.c_str());                  // K:2515
+  }
+  dr_context_destroy(ctx);
+  dr_scene_free(scene);
+  return 0;
+}

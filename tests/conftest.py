@@ -26,10 +26,8 @@ def _built():
     orc.build()
     if not os.path.exists(SCENEGEN) or os.path.getmtime(SCENEGEN) < os.path.getmtime(SCENEGEN + ".cpp"):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-o", SCENEGEN, SCENEGEN + ".cpp"])
-    import dogeray_amd
-    if not os.path.exists(os.path.join(ROOT, "dogeray_amd", "libdogeray_amd.so")):
-        from dogeray_amd import build as b
-        b.build()
+    from dogeray_amd import build as b
+    b.build()                     # no-op when libdogeray_amd.so and bin/dogeray are newer than their sources
     return True
 
 

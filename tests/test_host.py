@@ -210,3 +210,21 @@ def test_product_never_touches_the_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, flags=re.M), f
     out = subprocess.run(["ldd", os.path.join(ROOT, "dogeray_amd", "libdogeray_amd.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_host_application_reports_missing_gpu_or_renders(tmp_path):
+    """The C++ application (dogeray_main.cpp) speaks only the C ABI: with a GPU it renders and exports,
+    without one it stops at context creation with the library's error (no CPU rendering)."""
+    exe = os.path.join(ROOT, "dogeray_amd", "bin", "dogeray")
+    assert os.path.exists(exe)
+    out = str(tmp_path / "cube.bmp")
+    r = subprocess.run([exe, os.path.join(SCENES, "cube.rts"), "--textures", "", "--frames", "3", "--width", "128", "--height", "128",
+                        "--out", out, "--quiet"], capture_output=True, text=True, timeout=120)
+    assert "97 tris" in r.stdout and "194 nodes total" in r.stdout          # objnum = 96 + 1, bvhnum = 2 * 97 (K:2056,2094)
+    import torch
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stderr
+        data = open(out, "rb").read()
+        assert data[:2] == b"BM" and len(data) == 54 + 128 * 128 * 3
+    else:
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr
