@@ -117,6 +117,13 @@ def lib():
         if not os.path.exists(_LIB_PATH):
             raise ImportError("libdogeray_amd.so is missing: run `python -m dogeray_amd.build` "
                               "(or __graft_entry__.build()); dogeray_amd has no fallback path")
+        # One process must hold ONE HIP runtime.  PyTorch-ROCm ships its own libamdhip64; if this
+        # library pulled in /opt/rocm's copy first, torch's later initialisation finds "no HIP GPUs".
+        # Importing torch first (when it is installed) makes both resolve to the same runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(_LIB_PATH)
         for name, res, args in _API:
             f = getattr(L, name)
