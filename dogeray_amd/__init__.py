@@ -71,6 +71,8 @@ _API = [
     ("dr_abi_version", C.c_int, []),
     ("dr_scene_load", C.c_int, [C.c_char_p, C.c_char_p, C.POINTER(_VP)]),
     ("dr_scene_free", None, [_VP]),
+    ("dr_scene_create_from_arrays", C.c_int, [_VP, C.c_int, C.POINTER(DrSettings), _VP, C.c_int, C.POINTER(_VP)]),
+    ("dr_scene_add_texture", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_char_p]),
     ("dr_scene_num_objects", C.c_int, [_VP]),
     ("dr_scene_get_objects", C.c_int, [_VP, _VP]),
     ("dr_scene_get_settings", C.c_int, [_VP, C.POINTER(DrSettings)]),
@@ -171,6 +173,25 @@ class Scene:
         td = None if texture_dir is None else os.fsencode(texture_dir)
         _check(lib().dr_scene_load(os.fsencode(rts_path), td, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def from_arrays(cls, objects, settings=None, bvh=None, textures=()):
+        """objects: OBJECT_DTYPE[N + 1]; bvh: BVH_DTYPE[2 * (N + 1)] or None; textures: uint8[h, w, 4] arrays."""
+        objects = np.ascontiguousarray(objects, dtype=OBJECT_DTYPE)
+        n = len(objects) - 1
+        h = _VP()
+        bp, bn = None, 0
+        if bvh is not None:
+            bvh = np.ascontiguousarray(bvh, dtype=BVH_DTYPE)
+            bp, bn = _p(bvh), len(bvh)
+        _check(lib().dr_scene_create_from_arrays(_p(objects), n, C.byref(settings) if settings is not None else None, bp, bn, C.byref(h)))
+        sc = cls(h)
+        for i, t in enumerate(textures):
+            t = np.ascontiguousarray(t, dtype=np.uint8)
+            rc = lib().dr_scene_add_texture(h, _p(t), t.shape[1], t.shape[0], ("texture%d" % i).encode())
+            if rc < 0:
+                _check(rc)
+        return sc
 
     def close(self):
         if self._h:

@@ -39,6 +39,39 @@ int dr_scene_load(const char* rts_path, const char* texture_dir, dr_scene** out)
 
 void dr_scene_free(dr_scene* s) { delete s; }
 
+int dr_scene_create_from_arrays(const dr_object* objects, int n_objects, const dr_settings* settings,
+                                const dr_bvh_node* bvh, int bvhnum, dr_scene** out) {
+  if (!objects || !out || n_objects < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  *out = nullptr;
+  if (bvh && bvhnum != 2 * (n_objects + 1)) { set_error("bvhnum must be 2 * (n_objects + 1) (K:2073)"); return DR_ERR_INVALID; }
+  dr_scene* s = new (std::nothrow) dr_scene();
+  if (!s) { set_error("out of memory"); return DR_ERR_NOMEM; }
+  try {
+    s->host.n = n_objects;
+    s->host.objects.assign(objects, objects + n_objects + 1);
+    s->host.settings = settings ? *settings : default_settings();
+    if (bvh) {
+      s->host.bvh.assign(bvh, bvh + bvhnum);
+      s->host.bvh_used = 2 * n_objects - 1;
+    }
+  } catch (std::bad_alloc&) {
+    delete s;
+    set_error("out of memory");
+    return DR_ERR_NOMEM;
+  }
+  *out = s;
+  return DR_OK;
+}
+
+int dr_scene_add_texture(dr_scene* s, const uint8_t* rgba, int width, int height, const char* name) {
+  if (!s || !rgba || width <= 0 || height <= 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  HostTexture t;
+  t.w = width; t.h = height; t.path = name ? name : "";
+  t.rgba.assign(rgba, rgba + (size_t)width * height * 4);
+  s->host.textures.push_back(std::move(t));
+  return (int)s->host.textures.size() - 1;
+}
+
 int dr_scene_num_objects(const dr_scene* s) { return s ? s->host.n : DR_ERR_INVALID; }
 
 int dr_scene_get_objects(const dr_scene* s, dr_object* out) {

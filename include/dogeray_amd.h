@@ -92,6 +92,16 @@ typedef struct dr_settings {
 int dr_scene_load(const char* rts_path, const char* texture_dir, dr_scene** out);
 void dr_scene_free(dr_scene* s);
 
+/* The same scene from arrays the caller already holds -- what the reference's main() has after
+ * read()/build_bvh() (allobjects K:2061, nbvhtree K:2075, nanum/bvhnum K:1518,2073) and what it
+ * hands to CudaStarter.  objects: n_objects + 1 entries (the reference allocates one more than it
+ * fills).  bvh: bvhnum = 2 * (n_objects + 1) nodes from the caller's own build_bvh, or NULL to
+ * build later with dr_scene_build_bvh.  Everything is copied.  Textures are added in index order
+ * (dr_object.texnum / rtexnum and settings.backtex index this list, as texarray[] K:2077-2082). */
+int dr_scene_create_from_arrays(const dr_object* objects, int n_objects, const dr_settings* settings,
+                                const dr_bvh_node* bvh, int bvhnum, dr_scene** out);
+int dr_scene_add_texture(dr_scene* s, const uint8_t* rgba, int width, int height, const char* name);
+
 int dr_scene_num_objects(const dr_scene* s);            /* N = object lines (objnum - 1)   */
 int dr_scene_get_objects(const dr_scene* s, dr_object* out /* N + 1 entries */);
 int dr_scene_get_settings(const dr_scene* s, dr_settings* out);

@@ -345,3 +345,15 @@ def test_accumulator_tensor_aliases_device_memory(dr, ctx, synth):
     for r in range(3):
         back[r::3] = cols[r::3].contiguous()
     assert torch.equal(back, cols)
+
+
+def test_scene_from_arrays_renders_like_the_file(dr, ctx, synth):
+    src = dr.Scene.load(os.path.join(synth["dir"], "matball.rts"), synth["tex"])
+    src.build_bvh()
+    s = src.settings()
+    st = dr.pack_settings13(s, 1)
+    ctx.upload(src)
+    want = ctx.render_frame(st, 256, 256, s.background, 4)
+    twin = dr.Scene.from_arrays(src.objects(), s, bvh=src.bvh()[0], textures=src.textures())
+    ctx.upload(twin)
+    assert np.array_equal(ctx.render_frame(st, 256, 256, s.background, 4), want)

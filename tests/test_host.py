@@ -166,6 +166,23 @@ def test_random_field_is_reproducible(dr, tmp_path):
     assert 0 <= a["pos"][0][0] < 1 and a["pos"][0][0] != a["pos"][0][1]
 
 
+def test_scene_from_caller_arrays(dr, synth):
+    """The CudaStarter-level entry: objects (+ optionally the caller's own BVH) handed over as arrays."""
+    src = dr.Scene.load(os.path.join(SCENES, "cow.rts"), synth["tex"])
+    src.build_bvh()
+    nodes, used = src.bvh()
+    a = dr.Scene.from_arrays(src.objects(), src.settings(), bvh=nodes, textures=src.textures())
+    b = dr.Scene.from_arrays(src.objects(), src.settings(), textures=src.textures())
+    b.build_bvh()
+    for sc in (a, b):
+        assert sc.num_objects == src.num_objects
+        assert sc.objects().tobytes() == src.objects().tobytes()
+        assert sc.bvh()[0].tobytes() == nodes.tobytes() and sc.bvh()[1] == used
+        assert len(sc.textures()) == 7 and np.array_equal(sc.textures()[6], src.textures()[6])
+    with pytest.raises(dr.DogerayError):
+        dr.Scene.from_arrays(src.objects(), src.settings(), bvh=nodes[:-2])
+
+
 # ------------------------------------------------------------------------------ C ABI surface
 def header_functions():
     text = open(os.path.join(ROOT, "include", "dogeray_amd.h")).read()

@@ -28,7 +28,7 @@ for p in sorted(glob.glob(os.path.join(d, "pmc*"))):
             agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
         out.append("== PMC %s (mean per launch)" % os.path.relpath(f, d))
         for k, cs in agg.items():
-            if "render_kernel" not in k:
+            if "render_" not in k:
                 continue
             out.append("  " + k[:90])
             for cn, vals in sorted(cs.items()):
