@@ -105,7 +105,7 @@ _API = [
     ("dr_kat_tri", C.c_int, [_VP, C.c_int] + [_VP] * 6),
     ("dr_kat_sphere", C.c_int, [_VP, C.c_int] + [_VP] * 5),
     ("dr_kat_optics", C.c_int, [_VP, C.c_int] + [_VP] * 6),
-    ("dr_kat_hit", C.c_int, [_VP, C.c_int] + [_VP] * 4),
+    ("dr_kat_hit", C.c_int, [_VP, C.c_int] + [_VP] * 5),
 ]
 API_SYMBOLS = [a[0] for a in _API]
 
@@ -358,13 +358,14 @@ class Context:
         _check(lib().dr_kat_optics(self._h, n, _p(v), _p(nrm), _p(eta), _p(refl), _p(refr), _p(sch)))
         return refl, refr, sch
 
-    def kat_hit(self, o, d):
+    def kat_hit(self, o, d, want_visits=False):
         o, d = _f32(o), _f32(d)
         n = o.shape[0]
         t = np.zeros(n, dtype=np.float32)
         idx = np.zeros(n, dtype=np.int32)
-        _check(lib().dr_kat_hit(self._h, n, _p(o), _p(d), _p(t), _p(idx)))
-        return t, idx
+        vis = np.zeros(n, dtype=np.int32) if want_visits else None
+        _check(lib().dr_kat_hit(self._h, n, _p(o), _p(d), _p(t), _p(idx), _p(vis) if want_visits else None))
+        return (t, idx, vis) if want_visits else (t, idx)
 
 
 class ProgressiveRenderer:

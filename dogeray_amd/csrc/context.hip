@@ -100,9 +100,19 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   unsigned long long t_begin = 0, t_phase = 0, n_iter = 0, n_phase = 0;
   if (COUNT) t_begin = __builtin_readcyclecounter();
   ParkedLeaf pk; pk.P0 = pk.P1 = pk.P2 = make_float4(0, 0, 0, 0); pk.slot = 0; pk.parked = false;   // PARK_MIN > 0 only
+  int prio_now = 0;
   for (;;) {
     const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;
+    if (P.straggler_steps > 0) {
+      // A launch lasts at least as long as its longest pixel (thousands of dependent node visits).
+      // A wave that carries such a pixel gets issue priority over its SIMD neighbours.
+      const int want = __ballot(steps > (unsigned)P.straggler_steps) != 0ull ? 1 : 0;
+      if (want != prio_now) {
+        if (want) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+        prio_now = want;
+      }
+    }
     if (__popcll(walking) < TRAV_MIN) {
       unsigned long long t0 = 0;
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
@@ -322,7 +332,7 @@ __global__ void kat_optics_kernel(int n, const float* v, const float* nrm, const
   sch[i] = reflectance(a.x, eta[i]);
 }
 template <int MODE>
-__global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, const float* o, const float* d, float* t, int32_t* slot) {
+__global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, const float* o, const float* d, float* t, int32_t* slot, int32_t* visits) {
   __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : 1];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -330,11 +340,12 @@ __global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, con
   Hit h;
   if (MODE == DR_TRAVERSAL_ORDERED) {
     int* stack = lds_stack + (threadIdx.x >> 6) * (ORDERED_STACK * 64) + (threadIdx.x & 63);
-    h = closest_hit_ordered<false>(P.pairs, P.prims, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
+    h = closest_hit_ordered<true>(P.pairs, P.prims, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
   } else {
-    h = closest_hit_threaded<false>(walk_rsrc(P), ld3(o + 3 * i), ld3(d + 3 * i), c);
+    h = closest_hit_threaded<true>(walk_rsrc(P), ld3(o + 3 * i), ld3(d + 3 * i), c);
   }
   t[i] = h.t; slot[i] = h.slot;
+  if (visits) visits[i] = (int32_t)c.V;
 }
 
 }  // namespace dr
@@ -376,6 +387,7 @@ struct dr_context {
   int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
   int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
   int batch_frames = 8;     // persistent kernel: frames per launch in dr_render_accumulate
+  int straggler_steps = 0;  // persistent kernel: waves holding a pixel with more node steps than this get issue priority (0 = off)
   float cur_settings[13] = {0};
   dr_stats stats;
 };
@@ -468,6 +480,7 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   P.backtex = backtex;
   P.batch = 1;
   P.batch_seed_stride = 0;
+  P.straggler_steps = c->straggler_steps;
   return DR_OK;
 }
 
@@ -566,6 +579,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "park_min") { if (v != 0 && v != 8 && v != 16) goto bad; c->park_min = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
+  else if (name == "straggler_steps") { if (v < 0) goto bad; c->straggler_steps = v; }
   else { set_error("unknown option '" + name + "'"); return DR_ERR_INVALID; }
   return DR_OK;
 bad:
@@ -910,21 +924,22 @@ int dr_kat_optics(dr_context* c, int n, const float* v, const float* nrm, const 
   return b3.get(schlick, (size_t)n);
 }
 
-int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx) {
+int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx, int32_t* visits) {
   KAT_PRE(n);
   if (!c->walk) { set_error("no scene uploaded"); return DR_ERR_INVALID; }
-  DevBuf<float> bo, bd, bt; DevBuf<int32_t> bs;
+  DevBuf<float> bo, bd, bt; DevBuf<int32_t> bs, bv;
   size_t m = (size_t)n * 3;
-  KAT_DO(bo.alloc(m)); KAT_DO(bd.alloc(m)); KAT_DO(bt.alloc((size_t)n)); KAT_DO(bs.alloc((size_t)n));
+  KAT_DO(bo.alloc(m)); KAT_DO(bd.alloc(m)); KAT_DO(bt.alloc((size_t)n)); KAT_DO(bs.alloc((size_t)n)); KAT_DO(bv.alloc((size_t)n));
   KAT_DO(bo.put(o, m)); KAT_DO(bd.put(d, m));
   RenderParams P;
   memset(&P, 0, sizeof(P));
   P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims;
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (c->traversal == DR_TRAVERSAL_ORDERED) hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p);
-  else hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p);
+  if (c->traversal == DR_TRAVERSAL_ORDERED) hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p, bv.p);
+  else hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p, bv.p);
   HIP_TRY(hipStreamSynchronize(c->stream));
   KAT_DO(bt.get(t, (size_t)n));
+  if (visits) KAT_DO(bv.get(visits, (size_t)n));
   std::vector<int32_t> slots((size_t)n);
   KAT_DO(bs.get(slots.data(), (size_t)n));
   for (int i = 0; i < n; i++) idx[i] = slots[(size_t)i] >= 0 ? c->slot_to_orig[(size_t)slots[(size_t)i]] : 0;   // hit() returns index 0 on a miss (K:507)

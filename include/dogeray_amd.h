@@ -200,8 +200,9 @@ int dr_kat_sphere(dr_context* c, int n, const float* o, const float* d, const fl
                   const float* radius, float* t);
 int dr_kat_optics(dr_context* c, int n, const float* v, const float* nrm, const float* eta, float* refl,
                   float* refr, float* schlick);
-/* closest hit against the resident scene: t (-1 = miss) and ORIGINAL object index */
-int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx);
+/* closest hit against the resident scene: t (-1 = miss), ORIGINAL object index and (visits may be NULL)
+ * the number of boxes the chosen traversal tested for that ray */
+int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx, int32_t* visits);
 
 #ifdef __cplusplus
 }

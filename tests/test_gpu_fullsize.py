@@ -1,0 +1,108 @@
+"""BASELINE.json's full-size configuration on the GPU (C4 stand-in: 1 002 528 triangles, 1920x1080):
+size-independent properties + the oracle on a sampled set of block columns.  The scene file is the one
+bench.py generates and caches (tools/scenegen heightfield)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+W, H = 1920, 1080
+
+
+@pytest.fixture(scope="module")
+def big(tmp_path_factory):
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    import dogeray_amd as dr
+    assert dr.device_count() >= 1
+    path = bench.ensure_scene(os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"), 709, W, H)
+    scene = dr.Scene.load(path, "")
+    assert scene.num_objects == 1002528
+    scene.build_bvh()
+    ctx = dr.Context(0).upload(scene)
+    yield dr, scene, ctx, path
+    ctx.close()
+
+
+def test_bvh_is_the_reference_shape_at_1m(big):
+    dr, scene, ctx, path = big
+    nodes, used = scene.bvh()
+    n = scene.num_objects
+    assert used == 2 * n - 1 and len(nodes) == 2 * (n + 1)
+    live = nodes[nodes["active"] == 1]
+    leaf = live[live["end"] == 1]
+    assert len(leaf) == n and len(np.unique(leaf["under"])) == n
+    inner = live[live["end"] == 0]
+    assert np.array_equal(inner["children"][:, 1], inner["children"][:, 0] + 1)
+    depth = int(np.ceil(np.log2(n)))
+    assert depth == 20
+
+
+def test_frame_properties(big):
+    dr, scene, ctx, path = big
+    s = scene.settings()
+    st = dr.pack_settings13(s, 1, spp=1)
+    seed = 1 + 1000003 * 4
+    ctx.set_option("kernel", 1)
+    a = ctx.render_frame(st, W, H, s.background, seed)
+    assert np.array_equal(a, ctx.render_frame(st, W, H, s.background, seed))          # idempotent: same seed, same frame
+    assert not np.array_equal(a, ctx.render_frame(st, W, H, s.background, seed + 1))  # and the seed matters
+    ctx.set_option("kernel", 0)
+    assert np.array_equal(a, ctx.render_frame(st, W, H, s.background, seed))          # per-tile kernel: same frame
+    ctx.set_traversal(1)
+    assert np.array_equal(a, ctx.render_frame(st, W, H, s.background, seed))          # ordered traversal: same frame
+    ctx.set_traversal(0)
+    ctx.set_option("kernel", 1)
+    # stripes of 8 ranks compose to the full frame
+    total = np.zeros_like(a)
+    for r in range(8):
+        ctx.set_stripe(8, r)
+        total += ctx.render_frame(st, W, H, s.background, seed)
+    ctx.set_stripe(1, 0)
+    assert np.array_equal(total, a)
+    # a plausible image: the terrain fills roughly half the frame, nothing negative, sky pixels bright
+    assert a.min() >= 0 and 0.3 < (a.sum(axis=2) > 0).mean() <= 1.0
+
+
+def test_accumulation_is_the_sum_of_frames(big):
+    dr, scene, ctx, path = big
+    s = scene.settings()
+    st = dr.pack_settings13(s, 1, spp=1)
+    total = np.zeros((W, H, 3), dtype=np.int64)
+    for k in range(5):
+        total += ctx.render_frame(st, W, H, s.background, 77 + 1000003 * k)
+    ctx.accum_reset(W, H)
+    ctx.render_accumulate(st, W, H, s.background, 77, 1000003, 5)      # one batched launch
+    assert np.array_equal(ctx.accum_read().astype(np.int64), total)
+    img = ctx.accum_present(5)
+    want = np.clip(total // 5, 0, 255).astype(np.uint8).transpose(1, 0, 2)
+    assert np.array_equal(img, want)
+
+
+def test_sampled_columns_match_the_oracle(big):
+    """Every 24th 8-pixel block column of one full-size frame, pixel for pixel, plus the counters."""
+    dr, scene, ctx, path = big
+    from oracle import orc
+    osc = orc.Scene(path)
+    osc.build_bvh()
+    s = scene.settings()
+    st = dr.pack_settings13(s, 1, spp=1)
+    seed = 424242
+    mod = 24
+    ref, rc = osc.render(st, W, H, s.background, seed, nthreads=os.cpu_count() or 8, col_mod=mod, col_rem=5)
+    ctx.set_stripe(mod, 5)
+    ctx.enable_counters(True)
+    ctx.stats_reset()
+    got = ctx.render_frame(st, W, H, s.background, seed)
+    stats = ctx.stats()
+    ctx.enable_counters(False)
+    ctx.set_stripe(1, 0)
+    same = float(np.all(got == ref, axis=2).mean())
+    print("sampled columns: %.6f of pixels identical; %d rays" % (same, rc["rays"]))
+    assert same == 1.0
+    assert (stats["rays"], stats["node_visits"], stats["prim_tests"], stats["shades"]) == (rc["rays"], rc["V"], rc["L"], rc["S"])
