@@ -58,7 +58,8 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--traversal", choices=["threaded", "ordered"], default="threaded")
-    ap.add_argument("--gather-every", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch (default 8 x number of GPUs: a launch must outlast its longest pixel)")
+    ap.add_argument("--gather-every", type=int, default=0, help="frames between two gathers to rank 0 (default: --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-col-mod", type=int, default=1, help="cpu_baseline renders every n-th block column")
     ap.add_argument("--cache", default=os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"))
@@ -104,6 +105,11 @@ def main():
     mode = dr.TRAVERSAL_ORDERED if args.traversal == "ordered" else dr.TRAVERSAL_THREADED
     ctx.set_traversal(mode)
     ctx.set_stripe(world, rank)
+    if args.batch <= 0:
+        args.batch = 8 * world
+    if args.gather_every <= 0:
+        args.gather_every = args.batch
+    ctx.set_option("batch_frames", min(args.batch, 256))
     st = dr.pack_settings13(s, 1, spp=1)
     if rank == 0:
         log("scene %s: %d triangles, parse %.1fs, BVH %.1fs, upload %.2fs" % (os.path.basename(scene_path), ntris, t_parse, t_bvh, t_upload))
@@ -196,7 +202,7 @@ def main():
                         % (ntris, W, H, s.max_depth, args.traversal),
             "triangles": ntris, "width": W, "height": H, "spp_per_frame": 1, "max_depth": int(s.max_depth),
             "frames": frames, "parallelism": "framebuffer block-column stripes x%d" % world,
-            "gather_every": args.gather_every if world > 1 else None,
+            "gather_every": args.gather_every if world > 1 else None, "frames_per_launch": args.batch,
         },
         "rays_per_frame": rays / frames,
         "primary_samples_per_s": (W * H * frames) / elapsed,

@@ -100,19 +100,9 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   unsigned long long t_begin = 0, t_phase = 0, n_iter = 0, n_phase = 0;
   if (COUNT) t_begin = __builtin_readcyclecounter();
   ParkedLeaf pk; pk.P0 = pk.P1 = pk.P2 = make_float4(0, 0, 0, 0); pk.slot = 0; pk.parked = false;   // PARK_MIN > 0 only
-  int prio_now = 0;
   for (;;) {
     const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;
-    if (P.straggler_steps > 0) {
-      // A launch lasts at least as long as its longest pixel (thousands of dependent node visits).
-      // A wave that carries such a pixel gets issue priority over its SIMD neighbours.
-      const int want = __ballot(steps > (unsigned)P.straggler_steps) != 0ull ? 1 : 0;
-      if (want != prio_now) {
-        if (want) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-        prio_now = want;
-      }
-    }
     if (__popcll(walking) < TRAV_MIN) {
       unsigned long long t0 = 0;
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
@@ -275,12 +265,6 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __rest
   }
 }
 
-__global__ void zero_rect_kernel(int32_t* out, size_t n) {
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  size_t stride = (size_t)gridDim.x * blockDim.x;
-  for (; i < n; i += stride) out[i] = 0;
-}
-
 // clamp(acc / divide_by, 0, 255) into row-major RGB8 (draw loop K:2281-2287)
 __global__ void present_kernel(const int32_t* acc, uint8_t* rgb, int W, int H, int div) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -387,7 +371,6 @@ struct dr_context {
   int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
   int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
   int batch_frames = 8;     // persistent kernel: frames per launch in dr_render_accumulate
-  int straggler_steps = 0;  // persistent kernel: waves holding a pixel with more node steps than this get issue priority (0 = off)
   float cur_settings[13] = {0};
   dr_stats stats;
 };
@@ -480,7 +463,6 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   P.backtex = backtex;
   P.batch = 1;
   P.batch_seed_stride = 0;
-  P.straggler_steps = c->straggler_steps;
   return DR_OK;
 }
 
@@ -579,7 +561,6 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "park_min") { if (v != 0 && v != 8 && v != 16) goto bad; c->park_min = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
-  else if (name == "straggler_steps") { if (v < 0) goto bad; c->straggler_steps = v; }
   else { set_error("unknown option '" + name + "'"); return DR_ERR_INVALID; }
   return DR_OK;
 bad:

@@ -226,23 +226,16 @@ __device__ __forceinline__ void trav_step_park(WalkRsrc walk, V3 o, V3 inv, Trav
   const bool leaf = tr.node & 1;
   const unsigned off = (unsigned)(tr.node >> 1) << 4;
   float4 A = ld_unit(walk, off), B = ld_unit(walk, off + 16);
-  float4 P0 = A, P1 = A, P2 = A;
-  if (leaf) { P0 = ld_unit(walk, off + 32); P1 = ld_unit(walk, off + 48); P2 = ld_unit(walk, off + 64); }
+  // a stepping lane is not parked, so its parked record is free: the leaf's primitive lands there directly
+  if (leaf) { pk.P0 = ld_unit(walk, off + 32); pk.P1 = ld_unit(walk, off + 48); pk.P2 = ld_unit(walk, off + 64); }
   float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
   const int w0 = __float_as_int(A.w), miss = __float_as_int(B.w);
   float dist;
   if (COUNT) c.V++;
-  bool h = slab(o, inv, mn, mx, dist);
-  if (h && dist < tr.best_t) {
-    if (leaf) {
-      pk.P0 = P0; pk.P1 = P1; pk.P2 = P2; pk.slot = w0; pk.parked = true;
-      tr.node = miss;
-    } else {
-      tr.node = w0;
-    }
-  } else {
-    tr.node = miss;
-  }
+  bool h = slab(o, inv, mn, mx, dist) && dist < tr.best_t;
+  if (leaf) pk.slot = w0;
+  pk.parked = h && leaf;
+  tr.node = (h && !leaf) ? w0 : miss;
 }
 template <bool COUNT>
 __device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk, Ctr& c) {

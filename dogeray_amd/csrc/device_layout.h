@@ -108,8 +108,6 @@ struct RenderParams {
   int32_t accumulate;             // 0: store, 1: add into out, 2: atomic add (several frames in one launch)
   int32_t batch;                  // frames rendered by this launch (persistent kernel), >= 1
   uint64_t batch_seed_stride;     // frame f of the batch uses seed + f * batch_seed_stride
-  int32_t straggler_steps;        // persistent kernel: priority threshold (node steps of one pixel), 0 = off
-  int32_t pad2_;
 };
 
 }  // namespace dr

@@ -106,3 +106,46 @@ def test_sampled_columns_match_the_oracle(big):
     print("sampled columns: %.6f of pixels identical; %d rays" % (same, rc["rays"]))
     assert same == 1.0
     assert (stats["rays"], stats["node_visits"], stats["prim_tests"], stats["shades"]) == (rc["rays"], rc["V"], rc["L"], rc["S"])
+
+
+# The other BASELINE.json configs at their full sizes (stand-ins per SURVEY 8(d)): parity-test cases, not bench lines.
+@pytest.mark.parametrize("name,gen_args,Wc,Hc,tex,tris", [
+    ("C2 bunnyish 1280x720", ["bunnyish", "6", "1280", "720"], 1280, 720, False, 81922),
+    ("C5 city 3840x2160", ["city", "200", "3840", "2160"], 3840, 2160, False, 480002),
+    ("C3 textured 1920x1080", ["matball", "1920", "1080"], 1920, 1080, True, 86),
+])
+def test_other_configs_full_size(tmp_path, synth, name, gen_args, Wc, Hc, tex, tris):
+    import subprocess
+    import dogeray_amd as dr
+    from conftest import SCENEGEN
+    from oracle import orc
+    path = str(tmp_path / "scene.rts")
+    subprocess.check_call([SCENEGEN, gen_args[0], path] + gen_args[1:])
+    texdir = synth["tex"] if tex else ""
+    scene = dr.Scene.load(path, texdir)
+    assert scene.num_objects == tris
+    scene.build_bvh()
+    s = scene.settings()
+    assert (s.width, s.height) == (Wc, Hc)
+    ctx = dr.Context(0).upload(scene)
+    st = dr.pack_settings13(s, 1)
+    a = ctx.render_frame(st, Wc, Hc, s.background, 31337)
+    ctx.set_option("kernel", 0)
+    assert np.array_equal(a, ctx.render_frame(st, Wc, Hc, s.background, 31337))
+    ctx.set_traversal(1)
+    assert np.array_equal(a, ctx.render_frame(st, Wc, Hc, s.background, 31337))
+    ctx.set_traversal(0)
+    ctx.set_option("kernel", 1)
+    ctx.accum_reset(Wc, Hc)
+    ctx.render_accumulate(st, Wc, Hc, s.background, 31337, 1000003, 4)
+    acc = ctx.accum_read().astype(np.int64)
+    assert np.array_equal(acc[..., :] - a, sum(ctx.render_frame(st, Wc, Hc, s.background, 31337 + 1000003 * k).astype(np.int64) for k in (1, 2, 3)))
+    # the oracle on every 16th block column
+    osc = orc.Scene(path, texdir if tex else None)
+    osc.build_bvh()
+    ref, _ = osc.render(st, Wc, Hc, s.background, 31337, nthreads=os.cpu_count() or 8, col_mod=16, col_rem=3)
+    cols = (np.arange(Wc) // 8) % 16 == 3
+    same = float(np.all(a[cols] == ref[cols], axis=2).mean())
+    print("%s: %.6f of sampled pixels identical to the oracle" % (name, same))
+    assert same == 1.0
+    ctx.close()
