@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       // ---- test the parked leaves once enough lanes hold one (or nobody could step anyway)
       const unsigned long long parked = __ballot(pk.parked);
       const unsigned long long steppers = __ballot(tr.node >= 0 && !pk.parked);
-      if (parked != 0ull && (__popcll(parked) >= PARK_MIN || steppers == 0ull)) {
+      // (once the queue is empty the wave only drains: waiting for company just lengthens the tail)
+      if (parked != 0ull && (__popcll(parked) >= PARK_MIN || steppers == 0ull || cur_tile >= ntiles)) {
         if (pk.parked) parked_test<COUNT>(path.rayo, path.raydir, tr, pk, c);
       }
       // ---- one node step for every lane that is walking and not parked

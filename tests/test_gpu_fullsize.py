@@ -112,7 +112,7 @@ def test_sampled_columns_match_the_oracle(big):
 @pytest.mark.parametrize("name,gen_args,Wc,Hc,tex,tris", [
     ("C2 bunnyish 1280x720", ["bunnyish", "6", "1280", "720"], 1280, 720, False, 81922),
     ("C5 city 3840x2160", ["city", "200", "3840", "2160"], 3840, 2160, False, 480002),
-    ("C3 textured 1920x1080", ["matball", "1920", "1080"], 1920, 1080, True, 86),
+    ("C3 textured 1920x1080", ["matball", "1920", "1080"], 1920, 1080, True, 87),
 ])
 def test_other_configs_full_size(tmp_path, synth, name, gen_args, Wc, Hc, tex, tris):
     import subprocess
