@@ -79,10 +79,16 @@ def main():
     from dogeray_amd import multigpu
 
     dist = None
+    backend = os.environ.get("DOGERAY_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path on a box with fewer GPUs than ranks
+    ndev = dr.device_count()
+    device_index = local_rank if backend == "nccl" else local_rank % max(1, ndev)
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
 
     W, H = args.width, args.height
     t0 = time.time()
@@ -98,7 +104,7 @@ def main():
     t_bvh = time.time() - t0
     s = scene.settings()
     ntris = scene.num_objects
-    ctx = dr.Context(local_rank)
+    ctx = dr.Context(device_index)
     t0 = time.time()
     ctx.upload(scene)
     t_upload = time.time() - t0
@@ -116,7 +122,8 @@ def main():
 
     seed_base, seed_stride = 1, 1000003
     ctx.accum_reset(W, H)
-    acc = multigpu.accumulator_tensor(ctx, torch.device("cuda", local_rank)) if world > 1 else None
+    acc = multigpu.accumulator_tensor(ctx, torch.device("cuda", device_index)) if world > 1 else None
+    coll_dev = "cuda" if backend == "nccl" else "cpu"
 
     def run_frames(first, count):
         """Render frames [first, first+count) into the accumulator; gather every --gather-every frames."""
@@ -125,7 +132,7 @@ def main():
             n = min(args.gather_every, count - k) if world > 1 else count - k
             ctx.render_accumulate(st, W, H, s.background, seed_base + (first + k) * seed_stride, seed_stride, n)
             if world > 1:
-                multigpu.gather_frame(acc, W, H, world, rank)
+                multigpu.gather_frame(acc if backend == "nccl" else acc.cpu(), W, H, world, rank)
                 torch.cuda.synchronize()      # the gather reads the accumulator on torch's stream: finish before the next frames write it
             k += n
 
@@ -144,7 +151,7 @@ def main():
     elapsed = time.perf_counter() - t0
     timed = ctx.stats()
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -167,7 +174,7 @@ def main():
     rays_local = own["rays"]
     rays = rays_local
     if dist is not None:
-        rt = torch.tensor([rays_local], dtype=torch.int64, device="cuda")
+        rt = torch.tensor([rays_local], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(rt)
         rays = int(rt.item())
 

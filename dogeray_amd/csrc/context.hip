@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 //
 // lane states (kept in `tr.node`): >= 0 walking; -1 walk finished, needs shading; -2 needs a new
 // sample or pixel; -3 retired.
-template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN>
+template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL>
 __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, unsigned* __restrict__ pixel_cost) {
   const int lane = threadIdx.x & 63;
@@ -202,11 +202,15 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (parked != 0ull && (__popcll(parked) >= PARK_MIN || steppers == 0ull || cur_tile >= ntiles)) {
         if (pk.parked) parked_test<COUNT>(path.rayo, path.raydir, tr, pk, c);
       }
-      // ---- one node step for every lane that is walking and not parked
-      if (tr.node >= 0 && !pk.parked) {
-        if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
-        trav_step_park<COUNT>(walk, path.rayo, inv, tr, pk, c);
-        steps++;
+      // ---- UNROLL node steps for every lane that is walking and not parked (the bookkeeping above
+      // is then paid once per UNROLL steps; a lane that parks or finishes sits out the rest)
+#pragma unroll
+      for (int u = 0; u < P_UNROLL; u++) {
+        if (tr.node >= 0 && !pk.parked) {
+          if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
+          trav_step_park<COUNT>(walk, path.rayo, inv, tr, pk, c);
+          steps++;
+        }
       }
     } else {
       // ---- one node step for every walking lane
@@ -371,6 +375,7 @@ struct dr_context {
   int occupancy = 4;        // waves per SIMD the kernel is built and launched for
   int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
   int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
+  int unroll = 2;           // persistent kernel: node steps per loop iteration
   int batch_frames = 8;     // persistent kernel: frames per launch in dr_render_accumulate
   float cur_settings[13] = {0};
   dr_stats stats;
@@ -485,21 +490,24 @@ void launch_tile(dr_context* c, const RenderParams& P) {
   }
 }
 
-template <int OCC, int TRAV_MIN, int PARK_MIN>
+template <int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL = 1>
 void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pixel_cost) {
   int work = P.ncols * P.gy * P.batch;
   int blocks = c->num_cus * OCC;                   // OCC waves per SIMD on every CU
   if (blocks * 4 > work) blocks = (work + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
-  if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
-  else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
+  if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
+  else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
 }
 
 // The instantiated tunings; dr_context_set_option only accepts these values.
 template <int OCC>
 void launch_persistent_occ(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pcost) {
-  const int key = c->trav_min * 100 + c->park_min;
+  const int key = c->trav_min * 100 + c->park_min + 10000 * (c->unroll - 1);
   switch (key) {
+    case 13208: launch_persistent<OCC, 32, 8, 2>(c, P, counter, order, pcost); break;
+    case 13216: launch_persistent<OCC, 32, 16, 2>(c, P, counter, order, pcost); break;
+    case 23208: launch_persistent<OCC, 32, 8, 3>(c, P, counter, order, pcost); break;
     case 3200: launch_persistent<OCC, 32, 0>(c, P, counter, order, pcost); break;
     case 4800: launch_persistent<OCC, 48, 0>(c, P, counter, order, pcost); break;
     case 4808: launch_persistent<OCC, 48, 8>(c, P, counter, order, pcost); break;
@@ -560,6 +568,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "occupancy") { if (v != 4 && v != 5 && v != 6) goto bad; c->occupancy = v; }
   else if (name == "trav_min") { if (v != 32 && v != 48) goto bad; c->trav_min = v; }
   else if (name == "park_min") { if (v != 0 && v != 8 && v != 16) goto bad; c->park_min = v; }
+  else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
   else { set_error("unknown option '" + name + "'"); return DR_ERR_INVALID; }

@@ -300,7 +300,8 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
     base = None
     combos = [{"kernel": 0, "occupancy": 4}, {"kernel": 0, "occupancy": 6}, {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 8},
               {"kernel": 1, "occupancy": 5, "trav_min": 48, "park_min": 0}, {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 16},
-              {"kernel": 1, "occupancy": 4, "trav_min": 48, "park_min": 8, "feedback": 0}, {"kernel": 1, "batch_frames": 3}]
+              {"kernel": 1, "occupancy": 4, "trav_min": 48, "park_min": 8, "feedback": 0}, {"kernel": 1, "batch_frames": 3},
+              {"kernel": 1, "trav_min": 32, "park_min": 8, "unroll": 1}, {"kernel": 1, "unroll": 3}, {"kernel": 1, "park_min": 16, "unroll": 2}]
     for opts in combos:
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -311,7 +312,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         if base is None:
             base = acc
         assert np.array_equal(acc, base), opts
-    for k, v in {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 8}.items():
+    for k, v in {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 8, "unroll": 2}.items():
         ctx.set_option(k, v)
     with pytest.raises(dr.DogerayError):
         ctx.set_option("park_min", 7)
