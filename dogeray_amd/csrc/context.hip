@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   // diagnostic stamps (counting build only): wave lifetime, cycles inside the shade/refill phase
   unsigned long long t_begin = 0, t_phase = 0, n_iter = 0, n_phase = 0;
   if (COUNT) t_begin = __builtin_readcyclecounter();
-  ParkedLeaf pk; pk.P0 = pk.P1 = pk.P2 = make_float4(0, 0, 0, 0); pk.slot = 0; pk.parked = false;   // PARK_MIN > 0 only
+  ParkedLeaf pk; pk.v0x = 0; pk.C = pk.D = make_float4(0, 0, 0, 0); pk.info = 0; pk.parked = false;   // PARK_MIN > 0 only
   for (;;) {
     const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;

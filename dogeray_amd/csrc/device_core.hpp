@@ -156,6 +156,19 @@ __device__ __forceinline__ float prim_hit_regs(float4 A, float4 B, float4 C, V3 
   if (dist < 10000.0f && dist > -0.0f) return dist;          // K:449
   return -1.0f;
 }
+// the same on the walk array's leaf record: kind (WALK_KIND_*), v0 / centre, e1 (e1.x = radius), e2
+__device__ __forceinline__ float prim_hit_kind(int kind, V3 v0, V3 e1, V3 e2, V3 o, V3 d) {
+  float dist = -1.0f;
+  if (kind == WALK_KIND_TRIANGLE) dist = tri_hit(o, d, v0, e1, e2);
+  else if (kind == WALK_KIND_SPHERE) dist = sphere_hit(v0, e1.x, o, d);
+  if (dist < 10000.0f && dist > -0.0f) return dist;          // K:449
+  return -1.0f;
+}
+// successor of a leaf record at byte offset `off`: the next record (4 units on), or the end of the walk
+__device__ __forceinline__ int leaf_successor(unsigned off, int info) {
+  const int next = (int)(((off >> 4) + WALK_UNITS_LEAF) << 1) | ((info >> 28) & 1);
+  return (info >> 29) & 1 ? -1 : next;
+}
 __device__ __forceinline__ float prim_hit(const DevPrim* __restrict__ prims, int slot, V3 o, V3 d) {
   const float4* p = reinterpret_cast<const float4*>(prims + slot);
   return prim_hit_regs(p[0], p[1], p[2], o, d);
@@ -178,7 +191,7 @@ __device__ __forceinline__ void trav_begin(Trav& tr) { tr.node = 0; tr.best_t = 
 // The walk array is read through a buffer descriptor with 128-bit buffer loads: the compiler may
 // not re-slice those into narrower / unaligned pieces (it does so with plain float4 loads: the box
 // came in as dwordx2 + unaligned dwordx4 + dwordx3), so a node costs exactly two 16-byte requests
-// and a leaf five, all issued before the first wait.
+// and a leaf four, all issued before the first wait.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __amdgpu_buffer_rsrc_t WalkRsrc;
 __device__ __forceinline__ WalkRsrc walk_rsrc(const RenderParams& P) {
@@ -194,32 +207,33 @@ __device__ __forceinline__ void trav_step(WalkRsrc walk, V3 o, V3 d, V3 inv, Tra
   const bool leaf = tr.node & 1;
   const unsigned off = (unsigned)(tr.node >> 1) << 4;
   float4 A = ld_unit(walk, off), B = ld_unit(walk, off + 16);
-  float4 P0 = A, P1 = A, P2 = A;
-  if (leaf) { P0 = ld_unit(walk, off + 32); P1 = ld_unit(walk, off + 48); P2 = ld_unit(walk, off + 64); }
+  float4 C = A, D = A;
+  if (leaf) { C = ld_unit(walk, off + 32); D = ld_unit(walk, off + 48); }
   float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
-  const int w0 = __float_as_int(A.w), miss = __float_as_int(B.w);
+  const int w0 = __float_as_int(A.w);
+  const int next_miss = leaf ? leaf_successor(off, w0) : __float_as_int(B.w);
   float dist;
   if (COUNT) c.V++;
   bool h = slab(o, inv, mn, mx, dist);
   if (h && dist < tr.best_t) {
     if (leaf) {
       if (COUNT) c.L++;
-      float t = prim_hit_regs(P0, P1, P2, o, d);
-      if (t > -0.01f && t < tr.best_t) { tr.best_t = t; tr.best_slot = w0; }   // K:488 (t is -1 or > 0)
-      tr.node = miss;
+      float t = prim_hit_kind((w0 >> WALK_SLOT_BITS) & 3, mk(B.w, C.x, C.y), mk(C.z, C.w, D.x), mk(D.y, D.z, D.w), o, d);
+      if (t > -0.01f && t < tr.best_t) { tr.best_t = t; tr.best_slot = w0 & ((1 << WALK_SLOT_BITS) - 1); }   // K:488 (t is -1 or > 0)
+      tr.node = next_miss;
     } else {
       tr.node = w0;
     }
   } else {
-    tr.node = miss;
+    tr.node = next_miss;
   }
 }
 
 // Same step, but a leaf whose box passes is not tested on the spot: the lane keeps the primitive
-// record it has just fetched and waits ("parks") until enough lanes of the wave have one, so the
+// it has just fetched and waits ("parks") until enough lanes of the wave have one, so the
 // ~90-instruction triangle test runs once for many lanes instead of on nearly every iteration for
 // one or two.  The per-lane sequence of tests and updates is unchanged.
-struct ParkedLeaf { float4 P0, P1, P2; int slot; bool parked; };
+struct ParkedLeaf { float v0x; float4 C, D; int info; bool parked; };
 
 template <bool COUNT>
 __device__ __forceinline__ void trav_step_park(WalkRsrc walk, V3 o, V3 inv, Trav& tr, ParkedLeaf& pk, Ctr& c) {
@@ -227,21 +241,22 @@ __device__ __forceinline__ void trav_step_park(WalkRsrc walk, V3 o, V3 inv, Trav
   const unsigned off = (unsigned)(tr.node >> 1) << 4;
   float4 A = ld_unit(walk, off), B = ld_unit(walk, off + 16);
   // a stepping lane is not parked, so its parked record is free: the leaf's primitive lands there directly
-  if (leaf) { pk.P0 = ld_unit(walk, off + 32); pk.P1 = ld_unit(walk, off + 48); pk.P2 = ld_unit(walk, off + 64); }
+  if (leaf) { pk.C = ld_unit(walk, off + 32); pk.D = ld_unit(walk, off + 48); }
   float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
-  const int w0 = __float_as_int(A.w), miss = __float_as_int(B.w);
+  const int w0 = __float_as_int(A.w);
+  const int next_miss = leaf ? leaf_successor(off, w0) : __float_as_int(B.w);
   float dist;
   if (COUNT) c.V++;
   bool h = slab(o, inv, mn, mx, dist) && dist < tr.best_t;
-  if (leaf) pk.slot = w0;
+  if (leaf) { pk.info = w0; pk.v0x = B.w; }
   pk.parked = h && leaf;
-  tr.node = (h && !leaf) ? w0 : miss;
+  tr.node = (h && !leaf) ? w0 : next_miss;
 }
 template <bool COUNT>
 __device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk, Ctr& c) {
   if (COUNT) c.L++;
-  float t = prim_hit_regs(pk.P0, pk.P1, pk.P2, o, d);
-  if (t > -0.01f && t < tr.best_t) { tr.best_t = t; tr.best_slot = pk.slot; }   // K:488
+  float t = prim_hit_kind((pk.info >> WALK_SLOT_BITS) & 3, mk(pk.v0x, pk.C.x, pk.C.y), mk(pk.C.z, pk.C.w, pk.D.x), mk(pk.D.y, pk.D.z, pk.D.w), o, d);
+  if (t > -0.01f && t < tr.best_t) { tr.best_t = t; tr.best_slot = pk.info & ((1 << WALK_SLOT_BITS) - 1); }   // K:488
   pk.parked = false;
 }
 

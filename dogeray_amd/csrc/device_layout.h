@@ -7,10 +7,12 @@
 //
 //   walk    16-B units, one record per node in DFS pre-order (a subtree is one contiguous range):
 //             internal  2 units  {min.xyz, hit link} {max.xyz, miss link}
-//             leaf      5 units  {min.xyz, slot}     {max.xyz, miss link} + its primitive (3 units)
+//             leaf      4 units  {min.xyz, info} {max.xyz, v0.x} {v0.yz, e1.xy} {e1.z, e2.xyz}   (64 B)
 //           link = (unit index << 1) | target-is-leaf, -1 = end of the walk.  Knowing from the
 //           link that the target is a leaf lets the kernel fetch the box AND the triangle with
-//           one round trip instead of two dependent ones.
+//           one round trip instead of two dependent ones.  A leaf needs no miss link: its hit and
+//           miss links are equal (K:1738-1739) and in pre-order that successor is the next
+//           record, so `info` = slot | kind << 26 | next-is-leaf << 28 | last-node << 29.
 //   pairs   64 B   both children of an internal node     (ordered traversal: one fetch per step)
 //   prims   48 B   {v0.xyz, e1.x} {e1.yz, e2.xy} {e2.z, type, -, -}   hot intersection data,
 //                                                        in leaf (DFS) order: slot = leaf rank
@@ -28,7 +30,9 @@ struct DevUnit {       // 16 B; the walk array is made of these (read as float4 
   float f[4];
 };
 constexpr int WALK_UNITS_INTERNAL = 2;
-constexpr int WALK_UNITS_LEAF = 5;
+constexpr int WALK_UNITS_LEAF = 4;
+constexpr int WALK_SLOT_BITS = 26;                    // slots < 2^26 (the walk array itself is limited to 2^28 units)
+constexpr int WALK_KIND_SPHERE = 0, WALK_KIND_TRIANGLE = 1, WALK_KIND_NONE = 2;   // object type 0 / 2 / anything else
 
 // Ordered traversal: record k describes the two children of internal node k (pre-order index
 // of the internal node among ALL nodes is kept in `DevNode`; pairs are indexed by node id).

@@ -130,14 +130,27 @@ int linearise(const HostScene& sc, DeviceImage& img) {
       return (int32_t)((unit_of[(size_t)pre] << 1) | (sc.bvh[(size_t)order[(size_t)pre]].end ? 1 : 0));
     };
     img.walk.assign((size_t)unit_of[(size_t)used], DevUnit());
+    if (N > (1 << WALK_SLOT_BITS)) { set_error("scene too large for the walk array's slot field"); return DR_ERR_SCENE; }
     for (int k = 0; k < used; k++) {
       const dr_bvh_node& b = sc.bvh[(size_t)order[(size_t)k]];
       DevUnit* u = &img.walk[(size_t)unit_of[(size_t)k]];
-      int32_t w0 = b.end ? slot_of[(size_t)order[(size_t)k]] : link_to(k + 1);
-      int32_t w1 = link_to(b.miss_node < 0 ? -1 : new_id[(size_t)b.miss_node]);
-      memcpy(u[0].f, b.min, 12); memcpy(&u[0].f[3], &w0, 4);
-      memcpy(u[1].f, b.max, 12); memcpy(&u[1].f[3], &w1, 4);
-      if (b.end) memcpy(u[2].f, &img.prims[(size_t)slot_of[(size_t)order[(size_t)k]]], sizeof(DevPrim));
+      if (!b.end) {
+        int32_t w0 = link_to(k + 1);
+        int32_t w1 = link_to(b.miss_node < 0 ? -1 : new_id[(size_t)b.miss_node]);
+        memcpy(u[0].f, b.min, 12); memcpy(&u[0].f[3], &w0, 4);
+        memcpy(u[1].f, b.max, 12); memcpy(&u[1].f[3], &w1, 4);
+      } else {
+        const int slot = slot_of[(size_t)order[(size_t)k]];
+        const DevPrim& p = img.prims[(size_t)slot];
+        const int kind = p.type == 0 ? WALK_KIND_SPHERE : (p.type == 2 ? WALK_KIND_TRIANGLE : WALK_KIND_NONE);
+        const bool last = k + 1 >= used;
+        const bool next_leaf = !last && sc.bvh[(size_t)order[(size_t)k + 1]].end;
+        int32_t info = slot | (kind << WALK_SLOT_BITS) | ((next_leaf ? 1 : 0) << 28) | ((last ? 1 : 0) << 29);
+        memcpy(u[0].f, b.min, 12); memcpy(&u[0].f[3], &info, 4);
+        memcpy(u[1].f, b.max, 12); u[1].f[3] = p.v0[0];
+        u[2].f[0] = p.v0[1]; u[2].f[1] = p.v0[2]; u[2].f[2] = p.e1x; u[2].f[3] = p.e1y;
+        u[3].f[0] = p.e1z; u[3].f[1] = p.e2x; u[3].f[2] = p.e2y; u[3].f[3] = p.e2z;
+      }
     }
   }
 
