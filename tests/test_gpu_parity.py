@@ -358,3 +358,38 @@ def test_scene_from_arrays_renders_like_the_file(dr, ctx, synth):
     twin = dr.Scene.from_arrays(src.objects(), s, bvh=src.bvh()[0], textures=src.textures())
     ctx.upload(twin)
     assert np.array_equal(ctx.render_frame(st, 256, 256, s.background, 4), want)
+
+
+@pytest.mark.parametrize("kernel,mode", [(1, 0), (0, 0), (0, 1)])
+def test_fuzzed_scenes_render_like_the_oracle(dr, orc, ctx, synth, tmp_path, kernel, mode):
+    """Random scenes with spheres, all materials, textures, equal-t duplicates (tie-break = first leaf the
+    reference's walk reaches), zero-area and axis-aligned triangles, lens blur, spp > 1: frames identical."""
+    from scene_fuzz import random_scene
+    rng = np.random.default_rng(77)
+    names = ["synth_albedo.ppm", "synth_rough.ppm", "synth_env.ppm", "a.ppm"]
+    for k in range(12):
+        n = int(rng.integers(2, 600))
+        path = random_scene(rng, n, str(tmp_path / ("fuzz%d.rts" % k)), W=96, H=64, textures=names)
+        g, r, stats, rc = _render_pair(dr, orc, ctx, path, synth["tex"], 96, 64, 1, 1000 + k, mode=mode, kernel=kernel)
+        _assert_frames(g, r, "fuzz %d (%d objects) kernel %d traversal %d" % (k, n, kernel, mode))
+        assert stats["rays"] == rc["rays"] and stats["shades"] == rc["S"] and stats["texels"] == rc["T"]
+
+
+def test_equal_t_ties_go_to_the_first_leaf_in_reference_order(dr, orc, ctx, tmp_path):
+    """Two coincident triangles with different colours: hit() keeps the one its walk reaches first (K:488, strict <)."""
+    tri = "%s,2,%s,0.5,0,%s,1,%s"      # emissive (mat 1): the pixel shows which triangle won
+    a = ("-1.000000,-1.000000,0.000000", "1.000000,0.000000,0.000000", "1.000000,-1.000000,0.000000", "0.000000,1.000000,0.000000")
+    b = ("-1.000000,-1.000000,0.000000", "0.000000,1.000000,0.000000", "1.000000,-1.000000,0.000000", "0.000000,1.000000,0.000000")
+    far = ("-1.000000,-1.000000,-1.000000", "0.000000,0.000000,1.000000", "1.000000,-1.000000,-1.000000", "0.000000,1.000000,-1.000000")
+    winners = []
+    for order in ((a, b, far), (b, a, far), (far, b, a)):
+        p = tmp_path / "tie.rts"
+        p.write_text("*,0,0,3,0.0,0,0,0,3,40,4,1,1,no,64,64\n" + "\n".join(tri % t for t in order) + "\n")
+        for kernel, mode in ((1, 0), (0, 0), (0, 1)):
+            g, r, _, _ = _render_pair(dr, orc, ctx, str(p), "", 64, 64, 1, 5, mode=mode, kernel=kernel)
+            _assert_frames(g, r, "tie kernel %d traversal %d" % (kernel, mode))
+        lit = g[g.sum(axis=2) > 0]
+        hit_colours = {tuple(int(v > 0) for v in px) for px in lit if px.max() == 255 and sorted(px)[1] == 0}
+        winners.append(hit_colours & {(1, 0, 0), (0, 1, 0)})
+    # the coincident red / green pair: exactly one of them is ever seen, and swapping their order in the file swaps it
+    assert all(len(w) == 1 for w in winners[:2]) and winners[0] != winners[1]

@@ -245,3 +245,17 @@ def test_host_application_reports_missing_gpu_or_renders(tmp_path):
         assert data[:2] == b"BM" and len(data) == 54 + 128 * 128 * 3
     else:
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
+
+
+def test_fuzzed_scenes_parse_and_build_like_the_oracle(dr, orc, synth, tmp_path):
+    """Random scenes (mixed column counts, spheres, duplicates, degenerate triangles): objects and BVH identical."""
+    from scene_fuzz import random_scene
+    rng = np.random.default_rng(2024)
+    names = ["synth_albedo.ppm", "synth_rough.ppm", "synth_env.ppm", "a.ppm"]
+    for k in range(25):
+        n = int(rng.integers(2, 400))
+        path = random_scene(rng, n, str(tmp_path / ("fuzz%d.rts" % k)), textures=names)
+        ps, os_ = dr.Scene.load(path, synth["tex"]), orc.Scene(path, synth["tex"])
+        assert ps.num_objects == os_.n == n
+        assert_same_objects(ps, os_)
+        assert_same_bvh(ps, os_)
