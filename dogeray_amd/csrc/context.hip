@@ -67,7 +67,8 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // sample or pixel; -3 retired.
 template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL>
 __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
-                                                                     const int* __restrict__ tile_order, unsigned* __restrict__ pixel_cost) {
+                                                                     const int* __restrict__ tile_order, const int* __restrict__ region_start,
+                                                                     unsigned* __restrict__ pixel_cost) {
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int ntiles = P.ncols * P.gy;
@@ -82,9 +83,15 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   // A launch may cover a batch of frames (same view, consecutive seeds): position q is tile
   // order[q / batch] of frame q % batch, so the expensive tiles of ALL frames start first and the
   // tail of one frame (its longest paths) overlaps the bulk of the others.
+  // The queue is split into P.regions contiguous parts (tiles are numbered column by column, so a part
+  // is a band of the image).  With 8 regions every XCD drains "its" band first -- its 4 MiB L2 then holds
+  // the part of the scene that band sees instead of competing for all of it -- and helps the next band
+  // once its own is empty.  Region r owns positions [region_start[r], region_start[r+1]) of the order.
   int cur_tile = ntiles, cur_frame = 0;        // chunk being handed out; ntiles = none
-  if (wave_id < nwork) { const int t = wave_id / P.batch; cur_frame = wave_id - t * P.batch; cur_tile = tile_order ? tile_order[t] : t; }
-  int cur_next = 0;                // next unassigned lane-in-tile of cur_tile (64 = exhausted)
+  int cur_next = 64;               // next unassigned lane-in-tile of cur_tile (64 = exhausted: fetch first)
+  int region = 0, regions_left = P.regions;
+  if (P.regions > 1) region = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % (unsigned)P.regions);   // HW_REG_XCC_ID, 4 bits
+  (void)wave_id; (void)nwork;
   // per-lane path slot
   Trav tr; tr.node = -2; tr.best_t = 0; tr.best_slot = -1;
   Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
@@ -146,12 +153,23 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
       unsigned long long need = __ballot(want_pixel);
       while (need != 0ull) {
-        if (cur_next >= 64) {                      // wave-uniform: fetch the next tile
-          unsigned t = 0;
-          if (lane == 0) t = atomicAdd(tile_counter, 1u);
-          const int q = (int)__builtin_amdgcn_readfirstlane(t) + (int)gridDim.x * 4;   // positions 0 .. #waves-1 were the waves' first chunks
+        if (cur_next >= 64) {                      // wave-uniform: fetch the next chunk (tile, frame)
           cur_tile = ntiles;
-          if (q < nwork) { const int tt = q / P.batch; cur_frame = q - tt * P.batch; cur_tile = tile_order ? tile_order[tt] : tt; }
+          while (regions_left > 0) {
+            const int r0 = region_start ? region_start[region] : P.region_start[region];
+            const int r1 = region_start ? region_start[region + 1] : P.region_start[region + 1];
+            unsigned t = 0;
+            if (lane == 0) t = atomicAdd(tile_counter + region, 1u);
+            const int q = (int)__builtin_amdgcn_readfirstlane(t);
+            if (q < (r1 - r0) * P.batch) {
+              const int tt = q / P.batch;
+              cur_frame = q - tt * P.batch;
+              cur_tile = tile_order ? tile_order[r0 + tt] : r0 + tt;
+              break;
+            }
+            region = region + 1 == P.regions ? 0 : region + 1;   // this band is done: help with the next one
+            regions_left--;
+          }
           cur_next = 0;
         }
         if (cur_tile >= ntiles) {                  // frame exhausted: retire the lanes still asking
@@ -246,26 +264,35 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const unsigned* __restri
   for (int off = 32; off > 0; off >>= 1) { unsigned o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
   if ((threadIdx.x & 63) == 0) tile_cost[tile] = v;
 }
-// one workgroup: counting sort into ORDER_BUCKETS classes of 16 steps each, descending
+// one workgroup: counting sort by (region, cost class), cost classes of 16 steps each, descending
+// inside a region; region of a tile = the band of the tile numbering it falls in.
 constexpr int ORDER_BUCKETS = 256;
-__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __restrict__ tile_cost, int* __restrict__ order, int ntiles) {
-  __shared__ unsigned hist[ORDER_BUCKETS];
-  __shared__ unsigned base[ORDER_BUCKETS];
-  for (int i = threadIdx.x; i < ORDER_BUCKETS; i += blockDim.x) hist[i] = 0;
+constexpr int MAX_REGIONS = 8;
+__global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __restrict__ tile_cost, int* __restrict__ order,
+                                                           int* __restrict__ region_start, int ntiles, int regions) {
+  __shared__ unsigned hist[MAX_REGIONS * ORDER_BUCKETS];
+  __shared__ unsigned base[MAX_REGIONS * ORDER_BUCKETS];
+  const int nb = regions * ORDER_BUCKETS;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
   __syncthreads();
-  for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
+  auto key_of = [&](int t) {
     unsigned b = tile_cost[t] >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
-    atomicAdd(&hist[b], 1u);
-  }
+    const int r = (int)(((long long)t * regions) / ntiles);
+    return r * ORDER_BUCKETS + (ORDER_BUCKETS - 1 - (int)b);      // ascending key = region, then most expensive first
+  };
+  for (int t = threadIdx.x; t < ntiles; t += blockDim.x) atomicAdd(&hist[key_of(t)], 1u);
   __syncthreads();
   if (threadIdx.x == 0) {
     unsigned run = 0;
-    for (int b = ORDER_BUCKETS - 1; b >= 0; b--) { base[b] = run; run += hist[b]; }
+    for (int k = 0; k < nb; k++) {
+      if (k % ORDER_BUCKETS == 0) region_start[k / ORDER_BUCKETS] = (int)run;
+      base[k] = run; run += hist[k];
+    }
+    region_start[regions] = (int)run;
   }
   __syncthreads();
   for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
-    unsigned b = tile_cost[t] >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
-    unsigned pos = atomicAdd(&base[b], 1u);
+    unsigned pos = atomicAdd(&base[key_of(t)], 1u);
     order[pos] = t;
   }
 }
@@ -362,7 +389,7 @@ struct dr_context {
   unsigned long long* counters = nullptr;
   unsigned* tile_counters = nullptr; int tile_cursor = 0; int num_cus = 256;
   // cost feedback (persistent kernel): per-pixel cost of the last frame, per-tile cost, tile order
-  unsigned* pixel_cost = nullptr; unsigned* tile_cost = nullptr; int* tile_order = nullptr;
+  unsigned* pixel_cost = nullptr; unsigned* tile_cost = nullptr; int* tile_order = nullptr; int* region_start = nullptr;
   int order_capacity = 0;          // tiles the three buffers are sized for
   bool order_valid = false;        // tile_order was computed for `order_key`
   float order_key[16] = {0};       // settings13 + W, H, stripe of the frame the order belongs to
@@ -376,6 +403,7 @@ struct dr_context {
   int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
   int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
   int unroll = 2;           // persistent kernel: node steps per loop iteration
+  int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
   int batch_frames = 8;     // persistent kernel: frames per launch in dr_render_accumulate
   float cur_settings[13] = {0};
   dr_stats stats;
@@ -469,6 +497,12 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   P.backtex = backtex;
   P.batch = 1;
   P.batch_seed_stride = 0;
+  {
+    const int tiles = P.ncols * P.gy;
+    P.regions = c->xcd_regions ? MAX_REGIONS : 1;
+    if (tiles < 64 * MAX_REGIONS) P.regions = 1;                 // tiny frames: one queue
+    for (int r = 0; r <= MAX_REGIONS; r++) P.region_start[r] = r <= P.regions ? (int)(((long long)tiles * r + P.regions - 1) / P.regions) : tiles;
+  }
   return DR_OK;
 }
 
@@ -492,12 +526,13 @@ void launch_tile(dr_context* c, const RenderParams& P) {
 
 template <int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL = 1>
 void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pixel_cost) {
+  const int* rstart = order ? c->region_start : nullptr;        // identity order: the split travels in P.region_start
   int work = P.ncols * P.gy * P.batch;
   int blocks = c->num_cus * OCC;                   // OCC waves per SIMD on every CU
   if (blocks * 4 > work) blocks = (work + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
-  if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
-  else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL>), grid, block, 0, c->stream, P, counter, order, pixel_cost);
+  if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
+  else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
 }
 
 // The instantiated tunings; dr_context_set_option only accepts these values.
@@ -522,10 +557,11 @@ void feedback_buffers(dr_context* c, const RenderParams& P, int tiles, const int
   order = nullptr; pcost = nullptr;
   if (!c->feedback) return;
   if (c->order_capacity < tiles) {
-    for (void* b : {(void*)c->pixel_cost, (void*)c->tile_cost, (void*)c->tile_order}) if (b) (void)hipFree(b);
-    c->pixel_cost = nullptr; c->tile_cost = nullptr; c->tile_order = nullptr; c->order_capacity = 0; c->order_valid = false;
+    for (void* b : {(void*)c->pixel_cost, (void*)c->tile_cost, (void*)c->tile_order, (void*)c->region_start}) if (b) (void)hipFree(b);
+    c->pixel_cost = nullptr; c->tile_cost = nullptr; c->tile_order = nullptr; c->region_start = nullptr; c->order_capacity = 0; c->order_valid = false;
     if (hipMalloc((void**)&c->pixel_cost, (size_t)tiles * 64 * sizeof(unsigned)) == hipSuccess &&
         hipMalloc((void**)&c->tile_cost, (size_t)tiles * sizeof(unsigned)) == hipSuccess &&
+        hipMalloc((void**)&c->region_start, (MAX_REGIONS + 1) * sizeof(int)) == hipSuccess &&
         hipMalloc((void**)&c->tile_order, (size_t)tiles * sizeof(int)) == hipSuccess)
       c->order_capacity = tiles;
     else return;
@@ -533,7 +569,7 @@ void feedback_buffers(dr_context* c, const RenderParams& P, int tiles, const int
   // the stored order belongs to one view: same settings, size and stripe (progressive frames)
   float key[16] = {0};
   memcpy(key, c->cur_settings, 13 * sizeof(float));
-  key[13] = (float)P.W; key[14] = (float)P.H; key[15] = (float)(P.stripe_mod * 1024 + P.stripe_rem);
+  key[13] = (float)P.W; key[14] = (float)P.H; key[15] = (float)(P.stripe_mod * 1024 + P.stripe_rem) + 0.125f * (float)P.regions;
   if (c->order_valid && memcmp(c->order_key, key, sizeof(key)) == 0) order = c->tile_order;
   else { memcpy(c->order_key, key, sizeof(key)); c->order_valid = false; }
   pcost = c->pixel_cost;
@@ -543,18 +579,19 @@ void feedback_buffers(dr_context* c, const RenderParams& P, int tiles, const int
 void enqueue_frame(dr_context* c, const RenderParams& P) {
   const int tiles = P.ncols * P.gy;
   if (uses_persistent(c)) {
-    if (c->tile_cursor >= TILE_COUNTERS) {
+    if (c->tile_cursor + MAX_REGIONS > TILE_COUNTERS) {
       (void)hipMemsetAsync(c->tile_counters, 0, TILE_COUNTERS * sizeof(unsigned), c->stream);
       c->tile_cursor = 0;
     }
-    unsigned* counter = c->tile_counters + c->tile_cursor++;
+    unsigned* counter = c->tile_counters + c->tile_cursor;      // one counter per region
+    c->tile_cursor += MAX_REGIONS;
     const int* order; unsigned* pcost;
     feedback_buffers(c, P, tiles, order, pcost);
     if (c->occupancy == 5) launch_persistent_occ<5>(c, P, counter, order, pcost);
     else launch_persistent_occ<4>(c, P, counter, order, pcost);
     if (pcost) {   // next launch's order from this launch's costs (stream-ordered, no host sync)
       hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);
-      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, tiles);
+      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, c->region_start, tiles, P.regions);
       c->order_valid = true;
     }
     return;
@@ -568,6 +605,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "occupancy") { if (v != 4 && v != 5 && v != 6) goto bad; c->occupancy = v; }
   else if (name == "trav_min") { if (v != 32 && v != 48) goto bad; c->trav_min = v; }
   else if (name == "park_min") { if (v != 0 && v != 8 && v != 16) goto bad; c->park_min = v; }
+  else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
@@ -667,7 +705,7 @@ void dr_context_destroy(dr_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* bufs[] = {c->walk, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order};
+  void* bufs[] = {c->walk, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
