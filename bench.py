@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--traversal", choices=["threaded", "ordered"], default="threaded")
-    ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch (default 8 x number of GPUs: a launch must outlast its longest pixel)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch (default max(32, 8 x GPUs): a launch has to outlast its longest pixel, ~3 ms)")
     ap.add_argument("--gather-every", type=int, default=0, help="frames between two gathers to rank 0 (default: --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-col-mod", type=int, default=1, help="cpu_baseline renders every n-th block column")
@@ -112,7 +112,7 @@ def main():
     ctx.set_traversal(mode)
     ctx.set_stripe(world, rank)
     if args.batch <= 0:
-        args.batch = 8 * world
+        args.batch = max(32, 8 * world)
     if args.gather_every <= 0:
         args.gather_every = args.batch
     ctx.set_option("batch_frames", min(args.batch, 256))

@@ -404,7 +404,7 @@ struct dr_context {
   int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
-  int batch_frames = 8;     // persistent kernel: frames per launch in dr_render_accumulate
+  int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
   float cur_settings[13] = {0};
   dr_stats stats;
 };

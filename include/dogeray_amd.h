@@ -141,7 +141,7 @@ int dr_context_set_traversal(dr_context* c, int mode);
 /* Tuning knobs of the render kernels; none of them changes a pixel.
  *   "kernel"        DR_KERNEL_PERSISTENT (default): waves are pools of 64 path slots that refill
  *                   from a tile queue; DR_KERNEL_TILE: one wave per 8x8 tile, the reference's launch shape
- *   "batch_frames"  frames rendered per launch by dr_render_accumulate (persistent kernel), default 8
+ *   "batch_frames"  most frames one launch of dr_render_accumulate covers (persistent kernel), default 32
  *   "feedback"      1 (default): tiles are started most-expensive-first using the previous launch's costs
  *   "occupancy"     waves per SIMD (4 or 5; 6 for the tile kernel)
  *   "trav_min"      32 or 48;  "park_min"  0, 8 or 16;  "unroll"  1, 2 (default) or 3   (persistent kernel scheduling)
