@@ -11,7 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <dirent.h>
+#include <thread>
 #include <unistd.h>
+#include <utility>
 
 #include "scene_host.hpp"
 
@@ -188,9 +190,10 @@ inline bool is_no(Field f) { return f.n == 2 && f.p[0] == 'n' && f.p[1] == 'o'; 
 // (K:1098-1102,1308-1311), printed with to_string (6 decimals).  That is not reproducible;
 // here the value comes from a fixed-seed generator so that a scene loads the same way twice.
 struct FieldRandom {
-  uint64_t s = 0x853c49e6748fea9bull;
-  float next() {
-    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+  // a function of (line, column) only, so that the file can be parsed in pieces, in any order
+  static float at(long line, int col) {
+    uint64_t s = 0x853c49e6748fea9bull ^ ((uint64_t)line * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)(col + 1) * 0xC2B2AE3D27D4EB4Full);
+    s ^= s >> 33; s *= 0xff51afd7ed558ccdull; s ^= s >> 33; s *= 0xc4ceb9fe1a85ec53ull; s ^= s >> 33;
     double r = (double)(s >> 11) * (1.0 / 9007199254740992.0);
     char buf[32];
     snprintf(buf, sizeof(buf), "%f", r);
@@ -220,7 +223,7 @@ void apply_setting(HostScene& sc, int col, Field f, long line) {
   }
 }
 
-void apply_object(HostScene& sc, dr_object& o, int col, Field f, long line, FieldRandom& rnd) {
+void apply_object(const HostScene& sc, dr_object& o, int col, Field f, long line) {
   float fv = 0;
   int iv = 0;
   const bool is_r = (f.n == 1 && f.p[0] == 'r');
@@ -230,7 +233,7 @@ void apply_object(HostScene& sc, dr_object& o, int col, Field f, long line, Fiel
   if (col > 37) return;
   if (!name_col) {
     if (is_r) {
-      fv = rnd.next();
+      fv = FieldRandom::at(line, col);
       iv = (int)fv;   // stoi("0.xxxxxx") == 0
     } else if (int_col) {
       iv = field_int(f, line);
@@ -299,49 +302,113 @@ int read_rts(const char* path, HostScene& sc) {
   const char* p = data.data();
   const char* endp = p + data.size();
 
-  // getnum: lines whose first byte is neither '/' nor '*' (an empty line counts, K:1143-1152)
-  size_t nobj = 0;
-  for (const char* q = p; q < endp;) {
-    const char* nl = (const char*)memchr(q, '\n', (size_t)(endp - q));
-    const char* le = nl ? nl : endp;
-    char first = (le > q) ? *q : '\0';
-    if (first != '/' && first != '*') nobj++;
-    q = nl ? nl + 1 : endp;
+  // The file is cut into pieces at line boundaries and the pieces are converted by std::threads: object
+  // lines are independent of each other, and a piece knows where its objects go once the object lines of
+  // the pieces before it have been counted.  '*' lines are applied afterwards in file order (a later
+  // settings line overrides an earlier one, field by field).
+  struct Piece {
+    const char* b; const char* e;
+    size_t lines = 0, objects = 0;       // pass 1
+    size_t first_line = 0, first_object = 0;
+    std::vector<std::pair<const char*, const char*>> settings;   // '*' lines found
+    std::vector<long> settings_line;
+    bool failed = false; long err_line = 0; std::string err;
+  };
+  unsigned nthreads = std::thread::hardware_concurrency();
+  if (nthreads == 0) nthreads = 1;
+  size_t want = data.size() / (1 << 20) + 1;              // at least ~1 MB per piece
+  if (want < nthreads) nthreads = (unsigned)want;
+  std::vector<Piece> pieces(nthreads);
+  {
+    const char* b = p;
+    for (unsigned i = 0; i < nthreads; i++) {
+      const char* e = (i + 1 == nthreads) ? endp : p + data.size() * (i + 1) / nthreads;
+      if (e < b) e = b;
+      if (e < endp) { const char* nl = (const char*)memchr(e, '\n', (size_t)(endp - e)); e = nl ? nl + 1 : endp; }
+      pieces[i].b = b; pieces[i].e = e;
+      b = e;
+    }
   }
+  auto for_each_piece = [&](auto&& fn) {
+    if (nthreads == 1) { fn(pieces[0]); return; }
+    std::vector<std::thread> th;
+    for (unsigned i = 0; i < nthreads; i++) th.emplace_back([&, i]() { fn(pieces[i]); });
+    for (auto& t : th) t.join();
+  };
+  // pass 1 = getnum: lines whose first byte is neither '/' nor '*' (an empty line counts, K:1143-1152)
+  for_each_piece([&](Piece& pc) {
+    for (const char* q = pc.b; q < pc.e;) {
+      const char* nl = (const char*)memchr(q, '\n', (size_t)(pc.e - q));
+      const char* le = nl ? nl : pc.e;
+      char first = (le > q) ? *q : '\0';
+      pc.lines++;
+      if (first != '/' && first != '*') pc.objects++;
+      q = nl ? nl + 1 : pc.e;
+    }
+  });
+  size_t nobj = 0, nlines = 0;
+  for (Piece& pc : pieces) { pc.first_object = nobj; pc.first_line = nlines; nobj += pc.objects; nlines += pc.lines; }
   if (nobj > (size_t)INT32_MAX / 4) { set_error("scene too large"); return DR_ERR_SCENE; }
   sc.n = (int)nobj;
   sc.objects.assign(nobj + 1, default_object());   // objnum = count + 1 (K:1158); slot N untouched
 
-  FieldRandom rnd;
-  size_t obj = 0;
-  long line = 0;
-  try {
-    for (const char* q = p; q < endp;) {
-      const char* nl = (const char*)memchr(q, '\n', (size_t)(endp - q));
-      const char* le = nl ? nl : endp;
-      line++;
-      char first = (le > q) ? *q : '\0';
-      if (first != '/') {
-        const bool is_settings = first == '*';
-        // one iteration per comma-separated field, a trailing empty one included (K:1224,1303)
+  // pass 2 = read: one iteration per comma-separated field, a trailing empty one included (K:1224,1303)
+  for_each_piece([&](Piece& pc) {
+    size_t obj = pc.first_object;
+    long line = (long)pc.first_line;
+    try {
+      for (const char* q = pc.b; q < pc.e;) {
+        const char* nl = (const char*)memchr(q, '\n', (size_t)(pc.e - q));
+        const char* le = nl ? nl : pc.e;
+        line++;
+        char first = (le > q) ? *q : '\0';
+        if (first == '*') {
+          pc.settings.emplace_back(q, le);
+          pc.settings_line.push_back(line);
+        } else if (first != '/') {
+          int col = 0;
+          const char* f = q;
+          for (;;) {
+            const char* comma = (const char*)memchr(f, ',', (size_t)(le - f));
+            const char* fe = comma ? comma : le;
+            apply_object(sc, sc.objects[obj], col, Field{f, (size_t)(fe - f)}, line);
+            col++;
+            if (!comma) break;
+            f = comma + 1;
+          }
+          obj++;
+        }
+        q = nl ? nl + 1 : pc.e;
+      }
+    } catch (LineError& e) {
+      pc.failed = true; pc.err_line = line; pc.err = e.msg;
+    }
+  });
+  // settings lines, in file order; an error on an earlier line wins over one on a later line
+  long first_err_line = -1; std::string first_err;
+  for (Piece& pc : pieces) {
+    for (size_t k = 0; k < pc.settings.size() && first_err_line < 0; k++) {
+      if (pc.failed && pc.settings_line[k] > pc.err_line) break;
+      try {
         int col = 0;
-        const char* f = q;
+        const char* f = pc.settings[k].first; const char* le = pc.settings[k].second;
         for (;;) {
           const char* comma = (const char*)memchr(f, ',', (size_t)(le - f));
           const char* fe = comma ? comma : le;
-          Field fld{f, (size_t)(fe - f)};
-          if (is_settings) apply_setting(sc, col, fld, line);
-          else apply_object(sc, sc.objects[obj], col, fld, line, rnd);
+          apply_setting(sc, col, Field{f, (size_t)(fe - f)}, pc.settings_line[k]);
           col++;
           if (!comma) break;
           f = comma + 1;
         }
-        if (!is_settings) obj++;
+      } catch (LineError& e) {
+        first_err_line = pc.settings_line[k]; first_err = e.msg;
       }
-      q = nl ? nl + 1 : endp;
     }
-  } catch (LineError& e) {
-    set_error(std::string(path) + ": " + e.msg);
+    if (first_err_line >= 0) break;
+    if (pc.failed) { first_err_line = pc.err_line; first_err = pc.err; break; }
+  }
+  if (first_err_line >= 0) {
+    set_error(std::string(path) + ": " + first_err);
     return DR_ERR_PARSE;
   }
   return DR_OK;
