@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
                                                                      unsigned* __restrict__ pixel_cost) {
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  __shared__ int coop_lds[4 * COOP_STACK];     // one node stack per wave for the cooperative drain
   const int ntiles = P.ncols * P.gy;
   const int nwork = ntiles * P.batch;          // queue length: every tile of every frame of the batch
   const WalkRsrc walk = walk_rsrc(P);
@@ -101,6 +102,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   int frame = 0;                   // frame of the batch the pixel in this slot belongs to
   int pcode = 0;                   // tile * 64 + lane-in-tile of the pixel in this slot
   unsigned steps = 0;              // node steps spent on the pixel in this slot (the cost fed back)
+  unsigned rstart = 0;             // value of `steps` when the current ray started
   const bool degenerate = P.max_depth <= 0 || !(P.spp_f > 0.0f);
 
   // diagnostic stamps (counting build only): wave lifetime, cycles inside the shade/refill phase
@@ -133,6 +135,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           tr.node = -2;
         } else {
           trav_begin(tr);
+          rstart = steps;
           inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
           if (COUNT) c.rays++;
         }
@@ -206,11 +209,34 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           path.atten = splat(1.0f);
           bounce = 0;
           trav_begin(tr);
+          rstart = steps;
           inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
         }
       }
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
       if (__ballot(tr.node != -3) == 0ull) break;
+    }
+    if (!COUNT && P.coop_steps > 0 && cur_tile >= ntiles && __popcll(walking) <= P.coop_lanes) {
+      // ---- draining (the queue is empty) and only a few lanes of this wave still walk: a ray that is
+      // already old is finished by the whole wave at once (coop_closest_hit) instead of holding the launch
+      // open for hundreds of further dependent steps.  (The counting build keeps the plain walk so that
+      // its counters stay those of the reference order.)
+      unsigned long long cand = __ballot(tr.node >= 0 && !(PARK_MIN > 0 && pk.parked) && steps - rstart >= (unsigned)P.coop_steps);
+      while (cand != 0ull) {
+        const int L = __ffsll((long long)cand) - 1;
+        cand &= cand - 1ull;
+        auto bcast = [L](float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), L)); };
+        const V3 uo = mk(bcast(path.rayo.x), bcast(path.rayo.y), bcast(path.rayo.z));
+        const V3 ud = mk(bcast(path.raydir.x), bcast(path.raydir.y), bcast(path.raydir.z));
+        const V3 ui = mk(bcast(inv.x), bcast(inv.y), bcast(inv.z));
+        Hit r;
+        const bool done = coop_closest_hit(P.pairs, P.prims, uo, ud, ui, bcast(tr.best_t), __builtin_amdgcn_readlane(tr.best_slot, L),
+                                           coop_lds + (threadIdx.x >> 6) * COOP_STACK, r);
+        if (lane == L) {
+          if (done) { tr.best_t = r.t; tr.best_slot = r.slot; tr.node = -1; }
+          else rstart = 0x80000000u;              // stack overflow: never ask again for this ray (steps - rstart wraps below the threshold)
+        }
+      }
     }
     if (PARK_MIN > 0) {
       // ---- test the parked leaves once enough lanes hold one (or nobody could step anyway)
@@ -404,6 +430,8 @@ struct dr_context {
   int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
+  int coop_steps = 64;      // persistent kernel, drain phase: rays older than this are finished cooperatively (0 = off)
+  int coop_lanes = 8;       // ... in waves with at most this many lanes still walking
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
   float cur_settings[13] = {0};
   dr_stats stats;
@@ -497,6 +525,8 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   P.backtex = backtex;
   P.batch = 1;
   P.batch_seed_stride = 0;
+  P.coop_steps = c->coop_steps;
+  P.coop_lanes = c->coop_lanes;
   {
     const int tiles = P.ncols * P.gy;
     P.regions = c->xcd_regions ? MAX_REGIONS : 1;
@@ -605,6 +635,8 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "occupancy") { if (v != 4 && v != 5 && v != 6) goto bad; c->occupancy = v; }
   else if (name == "trav_min") { if (v != 32 && v != 48) goto bad; c->trav_min = v; }
   else if (name == "park_min") { if (v != 0 && v != 8 && v != 16) goto bad; c->park_min = v; }
+  else if (name == "coop_steps") { if (v < 0) goto bad; c->coop_steps = v; }
+  else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }

@@ -260,6 +260,90 @@ __device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk
   pk.parked = false;
 }
 
+// Cooperative closest hit: all 64 lanes of a wave answer ONE query.  The wave keeps a stack of internal
+// nodes (pair records) in LDS; per round every lane pops one, tests its two child boxes against the wave's
+// best t so far, tests leaf children on the spot and pushes internal children that pass.  A ray that costs
+// one lane a thousand dependent steps is finished in a few dozen rounds.  What comes out is the
+// lexicographic minimum (t, slot) over every leaf whose box and ancestors' boxes the ray enters nearer
+// than the best t -- the same hit as hit() K:468-512, on the same condition as the ordered traversal
+// (equal t goes to the lower slot = the leaf the reference's walk reaches first).  Used only while a
+// launch drains (persistent kernel): idle lanes shorten the few long rays that set the launch time.
+constexpr int COOP_STACK = 2048;          // entries per wave (8 KiB of LDS)
+
+__device__ __forceinline__ float wave_min_f32(float v) {
+  for (int off = 32; off > 0; off >>= 1) v = __builtin_fminf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+// returns false (and no result) if the stack would overflow; the caller then keeps walking the plain way
+__device__ __forceinline__ bool coop_closest_hit(const DevPair* __restrict__ pairs, const DevPrim* __restrict__ prims,
+                                                 V3 o, V3 d, V3 inv, float bound_t, int bound_slot,
+                                                 int* __restrict__ stack, Hit& out) {
+  const int lane = (int)__lane_id();
+  float best_t = bound_t;
+  int best_slot = bound_slot < 0 ? 0x7fffffff : bound_slot;
+  float prune_t = bound_t;
+  int n = 1;
+  if (lane == 0) stack[0] = 0;               // the root's pair
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  bool ok = true;
+  while (n > 0) {
+    const int take = n < 64 ? n : 64;
+    int pair = -1;
+    if (lane < take) pair = stack[n - 1 - lane];
+    n -= take;
+    bool push0 = false, push1 = false;
+    int c0 = 0, c1 = 0;
+    if (pair >= 0) {
+      const float4* pp = reinterpret_cast<const float4*>(pairs + pair);
+      float4 A = pp[0], B = pp[1], C = pp[2], D = pp[3];
+      c0 = __float_as_int(A.w); c1 = __float_as_int(B.w);
+      float mn0[3] = {A.x, A.y, A.z}, mx0[3] = {B.x, B.y, B.z};
+      float mn1[3] = {C.x, C.y, C.z}, mx1[3] = {D.x, D.y, D.z};
+      float d0, d1;
+      const bool h0 = slab(o, inv, mn0, mx0, d0) && d0 < prune_t;
+      const bool h1 = slab(o, inv, mn1, mx1, d1) && d1 < prune_t;
+      if (h0 && c0 < 0) {
+        const int slot = ~c0;
+        float t = prim_hit(prims, slot, o, d);
+        if (t > 0.0f && (t < best_t || (t == best_t && slot < best_slot))) { best_t = t; best_slot = slot; }
+      }
+      if (h1 && c1 < 0) {
+        const int slot = ~c1;
+        float t = prim_hit(prims, slot, o, d);
+        if (t > 0.0f && (t < best_t || (t == best_t && slot < best_slot))) { best_t = t; best_slot = slot; }
+      }
+      push0 = h0 && c0 >= 0;
+      push1 = h1 && c1 >= 0;
+    }
+    const unsigned long long m0 = __ballot(push0), m1 = __ballot(push1);
+    const int n0 = __popcll(m0), n1 = __popcll(m1);
+    if (n + n0 + n1 > COOP_STACK) { ok = false; break; }
+    __builtin_amdgcn_wave_barrier();            // every lane has read its entry before anyone overwrites it
+    if (push0) stack[n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] = c0;
+    if (push1) stack[n + n0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = c1;
+    n += n0 + n1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    prune_t = wave_min_f32(best_t);
+  }
+  if (!ok) return false;
+  // lexicographic minimum (t, slot) over the lanes
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ot = __shfl_xor(best_t, off, 64);
+    const int os = __shfl_xor(best_slot, off, 64);
+    const bool take_other = ot < best_t || (ot == best_t && os < best_slot);
+    best_t = take_other ? ot : best_t;
+    best_slot = take_other ? os : best_slot;
+  }
+  out.t = best_t;
+  out.slot = best_slot == 0x7fffffff ? -1 : best_slot;
+  return true;
+}
+
 __device__ __forceinline__ bool first_active_lane() { return __lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u; }
 
 template <bool COUNT>

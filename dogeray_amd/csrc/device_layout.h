@@ -112,6 +112,8 @@ struct RenderParams {
   int32_t accumulate;             // 0: store, 1: add into out, 2: atomic add (several frames in one launch)
   int32_t batch;                  // frames rendered by this launch (persistent kernel), >= 1
   uint64_t batch_seed_stride;     // frame f of the batch uses seed + f * batch_seed_stride
+  int32_t coop_steps;             // drain phase: a ray older than this many node steps is finished cooperatively (0 = never)
+  int32_t coop_lanes;             // ... in waves with at most this many lanes still walking
   int32_t regions;                // persistent kernel: number of tile queues (1, or 8 = one per XCD)
   int32_t region_start[9];        // identity order: region r owns tiles [region_start[r], region_start[r+1])
 };
