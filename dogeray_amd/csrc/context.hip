@@ -71,7 +71,13 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
                                                                      unsigned* __restrict__ pixel_cost) {
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
-  __shared__ int coop_lds[4 * COOP_STACK];     // one node stack per wave for the cooperative drain
+  // 6 KiB of LDS per wave, used for two things that never overlap in time within a wave:
+  //  * during the shade/refill phase, the state that phase does not need (the parked leaf, 1/direction,
+  //    and while a hit is shaded also the pixel bookkeeping) waits here -- the shading code is where
+  //    register pressure peaks, and this keeps the kernel at 96 VGPRs = 5 waves per SIMD;
+  //  * outside the phase, the node stack of the cooperative drain (COOP_STACK entries).
+  __shared__ int wave_lds[4 * WAVE_LDS_DWORDS];
+  int* const my_lds = wave_lds + (threadIdx.x >> 6) * WAVE_LDS_DWORDS;
   const int ntiles = P.ncols * P.gy;
   const int nwork = ntiles * P.batch;          // queue length: every tile of every frame of the batch
   const WalkRsrc walk = walk_rsrc(P);
@@ -115,10 +121,25 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
     if (__popcll(walking) < TRAV_MIN) {
       unsigned long long t0 = 0;
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
+      const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked);
+      bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
+      float* const st = reinterpret_cast<float*>(my_lds) + lane;      // slot k of this lane: st[k * 64]
+      {
+        st[0 * 64] = pk.v0x; st[1 * 64] = pk.C.x; st[2 * 64] = pk.C.y; st[3 * 64] = pk.C.z; st[4 * 64] = pk.C.w;
+        st[5 * 64] = pk.D.x; st[6 * 64] = pk.D.y; st[7 * 64] = pk.D.z; st[8 * 64] = pk.D.w;
+        st[9 * 64] = __int_as_float(pk.info); st[10 * 64] = pk.parked ? 1.0f : 0.0f;
+        st[11 * 64] = inv.x; st[12 * 64] = inv.y; st[13 * 64] = inv.z;
+        // pixel bookkeeping: not needed while the hit is shaded, back right after
+        st[14 * 64] = color.x; st[15 * 64] = color.y; st[16 * 64] = color.z;
+        st[17 * 64] = __int_as_float(px); st[18 * 64] = __int_as_float(py); st[19 * 64] = __int_as_float(pcode);
+        st[20 * 64] = __int_as_float(frame); st[21 * 64] = __int_as_float(sample);
+        st[22 * 64] = __uint_as_float(steps); st[23 * 64] = __uint_as_float(rstart);
+        asm volatile("" ::: "memory");           // the values must really travel through LDS (no forwarding in registers)
+      }
       // ---- shade the lanes whose walk has finished
-      if (tr.node == -1 && !(PARK_MIN > 0 && pk.parked)) {
-        bool ended;
-        V3 radiance = mk(0, 0, 0);
+      bool ended = false;
+      V3 radiance = mk(0, 0, 0);
+      if (shade_me) {
         if (tr.best_slot >= 0 && tr.best_t > 0.0f) {
           ended = !shade_hit<COUNT>(P, path, tr.best_t, tr.best_slot, rng, c, radiance);
           if (!ended) {
@@ -129,6 +150,15 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           radiance = shade_miss<COUNT>(P, path, c);
           ended = true;
         }
+      }
+      {
+        asm volatile("" ::: "memory");
+        color = mk(st[14 * 64], st[15 * 64], st[16 * 64]);
+        px = __float_as_int(st[17 * 64]); py = __float_as_int(st[18 * 64]); pcode = __float_as_int(st[19 * 64]);
+        frame = __float_as_int(st[20 * 64]); sample = __float_as_int(st[21 * 64]);
+        steps = __float_as_uint(st[22 * 64]); rstart = __float_as_uint(st[23 * 64]);
+      }
+      if (shade_me) {
         if (ended) {
           color = color + radiance;
           sample++;
@@ -136,7 +166,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         } else {
           trav_begin(tr);
           rstart = steps;
-          inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
+          fresh_ray = true;
           if (COUNT) c.rays++;
         }
       }
@@ -210,8 +240,16 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           bounce = 0;
           trav_begin(tr);
           rstart = steps;
-          inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
+          fresh_ray = true;
         }
+      }
+      {
+        asm volatile("" ::: "memory");
+        pk.v0x = st[0 * 64]; pk.C = make_float4(st[1 * 64], st[2 * 64], st[3 * 64], st[4 * 64]);
+        pk.D = make_float4(st[5 * 64], st[6 * 64], st[7 * 64], st[8 * 64]);
+        pk.info = __float_as_int(st[9 * 64]); pk.parked = st[10 * 64] != 0.0f;
+        inv = mk(st[11 * 64], st[12 * 64], st[13 * 64]);
+        if (fresh_ray) inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
       }
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
       if (__ballot(tr.node != -3) == 0ull) break;
@@ -231,7 +269,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         const V3 ui = mk(bcast(inv.x), bcast(inv.y), bcast(inv.z));
         Hit r;
         const bool done = coop_closest_hit(P.pairs, P.prims, uo, ud, ui, bcast(tr.best_t), __builtin_amdgcn_readlane(tr.best_slot, L),
-                                           coop_lds + (threadIdx.x >> 6) * COOP_STACK, r);
+                                           my_lds, r);
         if (lane == L) {
           if (done) { tr.best_t = r.t; tr.best_slot = r.slot; tr.node = -1; }
           else rstart = 0x80000000u;              // stack overflow: never ask again for this ray (steps - rstart wraps below the threshold)
@@ -425,7 +463,7 @@ struct dr_context {
   bool count = false;
   // tunables (dr_context_set_option / DOGERAY_OPTIONS)
   int kernel = DR_KERNEL_PERSISTENT;
-  int occupancy = 4;        // waves per SIMD the kernel is built and launched for
+  int occupancy = 5;        // waves per SIMD the kernel is built and launched for (persistent: 4 or 5; tile kernel: 4 or 6)
   int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
   int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
   int unroll = 2;           // persistent kernel: node steps per loop iteration
@@ -617,7 +655,7 @@ void enqueue_frame(dr_context* c, const RenderParams& P) {
     c->tile_cursor += MAX_REGIONS;
     const int* order; unsigned* pcost;
     feedback_buffers(c, P, tiles, order, pcost);
-    if (c->occupancy == 5) launch_persistent_occ<5>(c, P, counter, order, pcost);
+    if (c->occupancy >= 5) launch_persistent_occ<5>(c, P, counter, order, pcost);
     else launch_persistent_occ<4>(c, P, counter, order, pcost);
     if (pcost) {   // next launch's order from this launch's costs (stream-ordered, no host sync)
       hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);

@@ -143,7 +143,7 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   from a tile queue; DR_KERNEL_TILE: one wave per 8x8 tile, the reference's launch shape
  *   "batch_frames"  most frames one launch of dr_render_accumulate covers (persistent kernel), default 32
  *   "feedback"      1 (default): tiles are started most-expensive-first using the previous launch's costs
- *   "occupancy"     waves per SIMD (4 or 5; 6 for the tile kernel)
+ *   "occupancy"     waves per SIMD: 5 (default) or 4 for the persistent kernel, 4 or 6 for the tile kernel
  *   "trav_min"      32 or 48;  "park_min"  0, 8 or 16;  "unroll"  1, 2 (default) or 3   (persistent kernel scheduling)
  *   "xcd_regions"   1 (default): one tile queue per XCD, each an image band, with stealing; 0: one queue
  *   "coop_steps"    once the tile queue is empty, a ray older than this many node steps is finished by all 64

@@ -312,7 +312,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         if base is None:
             base = acc
         assert np.array_equal(acc, base), opts
-    for k, v in {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2}.items():
+    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2}.items():
         ctx.set_option(k, v)
     with pytest.raises(dr.DogerayError):
         ctx.set_option("park_min", 7)
