@@ -58,10 +58,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // as fewer than TRAV_MIN lanes are still walking, the finished lanes are shaded (hit or miss),
 // scatter into their next ray, or -- when their path has ended -- store their pixel and take the
 // next unrendered pixel, so the node loop stays full until the frame runs out of pixels.
-// Pixels are handed out in 8x8 tiles from one global counter (first tile = wave id, then
-// atomicAdd), lane l of a tile is pixel (l >> 3, l & 7) of that tile: which lane renders a pixel
-// does not enter its arithmetic (the RNG seed is a function of x, y and the frame, K:1065), so
-// the frame is identical to the per-tile kernel's.
+// Pixels are handed out in 8x8 tiles from per-XCD queues (one atomicAdd per tile), lane l of a tile is
+// pixel (l >> 3, l & 7) of that tile: which lane renders a pixel does not enter its arithmetic (the RNG
+// seed is a function of x, y and the frame, K:1065), so the frame is identical to the per-tile kernel's.
 //
 // lane states (kept in `tr.node`): >= 0 walking; -1 walk finished, needs shading; -2 needs a new
 // sample or pixel; -3 retired.

@@ -393,3 +393,18 @@ def test_equal_t_ties_go_to_the_first_leaf_in_reference_order(dr, orc, ctx, tmp_
         winners.append(hit_colours & {(1, 0, 0), (0, 1, 0)})
     # the coincident red / green pair: exactly one of them is ever seen, and swapping their order in the file swaps it
     assert all(len(w) == 1 for w in winners[:2]) and winners[0] != winners[1]
+
+
+@pytest.mark.parametrize("kernel", [0, 1])
+def test_degenerate_settings(dr, orc, ctx, tmp_path, kernel):
+    """spp 0, depth 0 and odd frame sizes (margins, K:2633): zeros where the reference computes nothing."""
+    src = os.path.join(SCENES, "cube.rts")
+    for line, W, H in (("*,7.358891,-6.925791,4.958309,0.01,0,0,0,3,45,0,1,1,no,100,70", 100, 70),     # depth 0
+                       ("*,7.358891,-6.925791,4.958309,0.01,0,0,0,3,45,5,0,1,no,100,70", 100, 70),     # spp 0
+                       ("*,7.358891,-6.925791,4.958309,0.01,0,0,0,3,45,3,2,1,no,37,23", 37, 23),       # 4 x 2 tiles + margins
+                       ("*,7.358891,-6.925791,4.958309,0.01,0,0,0,3,45,3,1,1,no,7,200", 7, 200)):      # narrower than one tile: nothing rendered
+        path = with_settings(src, str(tmp_path / "d.rts"), line)
+        g, r, stats, rc = _render_pair(dr, orc, ctx, path, "", W, H, 1, 9, kernel=kernel)
+        _assert_frames(g, r, "degenerate %dx%d kernel %d" % (W, H, kernel))
+        assert stats["rays"] == rc["rays"]
+        assert not g[(W // 8) * 8:].any() and not g[:, (H // 8) * 8:].any()
