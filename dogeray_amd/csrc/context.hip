@@ -327,36 +327,72 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const unsigned* __restri
   for (int off = 32; off > 0; off >>= 1) { unsigned o = __shfl_xor(v, off, 64); v = o > v ? o : v; }
   if ((threadIdx.x & 63) == 0) tile_cost[tile] = v;
 }
-// one workgroup: counting sort by (region, cost class), cost classes of 16 steps each, descending
-// inside a region; region of a tile = the band of the tile numbering it falls in.
+// One workgroup builds the next launch's tile order.  Per region (band of the tile numbering): first the
+// EXPENSIVE tiles (cost above `heavy_factor` x the mean), most expensive first -- they set the length of a
+// launch, so they start first; then all other tiles in their natural order, so that the waves of an XCD walk
+// their band coherently (neighbouring tiles see neighbouring parts of the scene).
 constexpr int ORDER_BUCKETS = 256;
 constexpr int MAX_REGIONS = 8;
 __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __restrict__ tile_cost, int* __restrict__ order,
-                                                           int* __restrict__ region_start, int ntiles, int regions) {
-  __shared__ unsigned hist[MAX_REGIONS * ORDER_BUCKETS];
+                                                           int* __restrict__ region_start, int ntiles, int regions, int heavy_factor) {
+  __shared__ unsigned hist[MAX_REGIONS * ORDER_BUCKETS];   // expensive tiles per (region, cost class)
   __shared__ unsigned base[MAX_REGIONS * ORDER_BUCKETS];
+  __shared__ unsigned light_in_region[MAX_REGIONS], light_before[MAX_REGIONS], heavy_in_region[MAX_REGIONS];
+  __shared__ unsigned scan[1024];
+  __shared__ unsigned long long total_cost;
   const int nb = regions * ORDER_BUCKETS;
-  for (int i = threadIdx.x; i < nb; i += blockDim.x) hist[i] = 0;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nb; i += blockDim.x) hist[i] = 0;
+  if (tid < MAX_REGIONS) { light_in_region[tid] = 0; heavy_in_region[tid] = 0; }
+  if (tid == 0) total_cost = 0;
   __syncthreads();
-  auto key_of = [&](int t) {
-    unsigned b = tile_cost[t] >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
-    const int r = (int)(((long long)t * regions) / ntiles);
-    return r * ORDER_BUCKETS + (ORDER_BUCKETS - 1 - (int)b);      // ascending key = region, then most expensive first
-  };
-  for (int t = threadIdx.x; t < ntiles; t += blockDim.x) atomicAdd(&hist[key_of(t)], 1u);
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned run = 0;
-    for (int k = 0; k < nb; k++) {
-      if (k % ORDER_BUCKETS == 0) region_start[k / ORDER_BUCKETS] = (int)run;
-      base[k] = run; run += hist[k];
-    }
-    region_start[regions] = (int)run;
+  // every thread owns one contiguous chunk of tiles (so that "natural order" is a plain prefix sum)
+  const int chunk = (ntiles + (int)blockDim.x - 1) / (int)blockDim.x;
+  const int t0 = tid * chunk, t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
+  {
+    unsigned long long sum = 0;
+    for (int t = t0; t < t1; t++) sum += tile_cost[t];
+    atomicAdd(&total_cost, sum);
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < ntiles; t += blockDim.x) {
-    unsigned pos = atomicAdd(&base[key_of(t)], 1u);
-    order[pos] = t;
+  const unsigned long long threshold = heavy_factor > 0 ? (total_cost * (unsigned long long)heavy_factor) / (unsigned long long)(ntiles > 0 ? ntiles : 1) : ~0ull;
+  auto region_of = [&](int t) { return (int)(((long long)t * regions) / ntiles); };
+  auto heavy = [&](int t) { return (unsigned long long)tile_cost[t] > threshold; };
+  auto key_of = [&](int t) {
+    unsigned b = tile_cost[t] >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
+    return region_of(t) * ORDER_BUCKETS + (ORDER_BUCKETS - 1 - (int)b);      // ascending key = region, then most expensive first
+  };
+  unsigned my_light = 0;
+  for (int t = t0; t < t1; t++) {
+    if (heavy(t)) { atomicAdd(&hist[key_of(t)], 1u); atomicAdd(&heavy_in_region[region_of(t)], 1u); }
+    else { my_light++; atomicAdd(&light_in_region[region_of(t)], 1u); }
+  }
+  scan[tid] = my_light;
+  __syncthreads();
+  if (tid == 0) {
+    unsigned run = 0;                                   // exclusive scan of the per-thread light counts
+    for (int i = 0; i < (int)blockDim.x; i++) { unsigned v = scan[i]; scan[i] = run; run += v; }
+    unsigned pos = 0, lights = 0;
+    for (int r = 0; r < regions; r++) {
+      region_start[r] = (int)pos;
+      for (int k = 0; k < ORDER_BUCKETS; k++) { base[r * ORDER_BUCKETS + k] = pos; pos += hist[r * ORDER_BUCKETS + k]; }
+      light_before[r] = lights;                         // light tiles in the regions before r
+      heavy_in_region[r] = pos;                         // from here on: where region r's light tiles begin
+      pos += light_in_region[r];
+      lights += light_in_region[r];
+    }
+    region_start[regions] = (int)pos;
+  }
+  __syncthreads();
+  unsigned light_rank = scan[tid];                      // global rank of this thread's first light tile
+  for (int t = t0; t < t1; t++) {
+    if (heavy(t)) {
+      order[atomicAdd(&base[key_of(t)], 1u)] = t;
+    } else {
+      const int r = region_of(t);
+      order[heavy_in_region[r] + (light_rank - light_before[r])] = t;
+      light_rank++;
+    }
   }
 }
 
@@ -467,6 +503,7 @@ struct dr_context {
   int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
+  int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural)
   int coop_steps = 64;      // persistent kernel, drain phase: rays older than this are finished cooperatively (0 = off)
   int coop_lanes = 8;       // ... in waves with at most this many lanes still walking
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
@@ -658,7 +695,7 @@ void enqueue_frame(dr_context* c, const RenderParams& P) {
     else launch_persistent_occ<4>(c, P, counter, order, pcost);
     if (pcost) {   // next launch's order from this launch's costs (stream-ordered, no host sync)
       hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);
-      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, c->region_start, tiles, P.regions);
+      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, c->region_start, tiles, P.regions, c->heavy_factor);
       c->order_valid = true;
     }
     return;
@@ -672,6 +709,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "occupancy") { if (v != 4 && v != 5 && v != 6) goto bad; c->occupancy = v; }
   else if (name == "trav_min") { if (v != 32 && v != 48) goto bad; c->trav_min = v; }
   else if (name == "park_min") { if (v != 0 && v != 8 && v != 16) goto bad; c->park_min = v; }
+  else if (name == "heavy_factor") { if (v < 0 || v > 1000) goto bad; c->heavy_factor = v; c->order_valid = false; }
   else if (name == "coop_steps") { if (v < 0) goto bad; c->coop_steps = v; }
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
