@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
       if (__ballot(tr.node != -3) == 0ull) break;
     }
-    if (!COUNT && P.coop_steps > 0 && cur_tile >= ntiles && __popcll(walking) <= P.coop_lanes) {
+    if (!COUNT && P.coop_steps > 0 && cur_tile >= ntiles && (int)__popcll(walking) <= P.coop_lanes) {
       // ---- draining (the queue is empty) and only a few lanes of this wave still walk: a ray that is
       // already old is finished by the whole wave at once (coop_closest_hit) instead of holding the launch
       // open for hundreds of further dependent steps.  (The counting build keeps the plain walk so that
@@ -285,8 +285,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
       // ---- UNROLL node steps for every lane that is walking and not parked (the bookkeeping above
       // is then paid once per UNROLL steps; a lane that parks or finishes sits out the rest)
-#pragma unroll
-      for (int u = 0; u < P_UNROLL; u++) {
+      for (int u = 0; u < P_UNROLL; u++) {     // P_UNROLL is a template constant: fully unrolled by the optimizer
         if (tr.node >= 0 && !pk.parked) {
           if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
           trav_step_park<COUNT>(walk, path.rayo, inv, tr, pk, c);
