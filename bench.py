@@ -43,6 +43,50 @@ def ensure_scene(cache_dir, verts, W, H):
     return path
 
 
+def measure_traffic(args):
+    """HBM-side bytes per render-kernel launch from rocprofv3 PMC counters, each counter in its own pass
+    (MI355X_MICROARCH.md, HBM / rocprofv3 sections): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
+    reports half the bytes of 16-byte-per-lane reads, so it is doubled (calibrated for streaming reads; taken
+    over for this kernel's 16-byte gathers).  Runs this script as a child under rocprofv3; returns None on any problem."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="dogeray_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+                   "--steps", str(args.steps), "--warmup", str(max(args.warmup, args.steps)), "--batch", str(args.batch), "--traversal", args.traversal,
+                   "--verts", str(args.verts), "--width", str(args.width), "--height", str(args.height), "--cache", args.cache,
+                   "--no-cpu-baseline", "--no-traffic"]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, env=env, cwd="/tmp")
+            if r.returncode != 0:
+                return None
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    # the timed launches only: the non-counting build of the render kernel
+                    if row["Counter_Name"] == counter and "render_" in row["Kernel_Name"] and "<false" in row["Kernel_Name"]:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None
+            full = max(vals)                      # launches that cover a full batch report the largest value
+            vals = [v for v in vals if v > 0.8 * full]
+            out[counter] = sum(vals) / len(vals) * 1024.0
+        return {"bytes_per_launch": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "fetch_size_bytes_raw": out["FETCH_SIZE"],
+                "write_size_bytes": out["WRITE_SIZE"]}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def algorithmic_bytes(c, frames, W, H):
     """32 B per node visit, 36 B per triangle test, 128 B per shaded hit, 4 B per texel,
     12 B per pixel written per frame."""
@@ -61,6 +105,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch (default max(32, 8 x GPUs): a launch has to outlast its longest pixel, ~3 ms)")
     ap.add_argument("--gather-every", type=int, default=0, help="frames between two gathers to rank 0 (default: --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
     ap.add_argument("--cpu-col-mod", type=int, default=1, help="cpu_baseline renders every n-th block column")
     ap.add_argument("--cache", default=os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"))
     args = ap.parse_args()
@@ -74,14 +119,24 @@ def main():
             sys.exit(2)
         args.gpus = world
 
+    if args.batch <= 0:
+        args.batch = max(32, 8 * world)
+    # HBM traffic of the timed kernel: rocprofv3 PMC passes over child runs of this same command.  Done first,
+    # before this process touches the GPU (a process that has initialised HIP should not spawn programs).
+    traffic_probe = None
+    if world == 1 and not args.no_traffic:
+        ensure_scene(args.cache, args.verts, args.width, args.height)
+        t0 = time.time()
+        traffic_probe = measure_traffic(args)
+        log("traffic probe (2 rocprofv3 passes): %.1f s -> %s" % (time.time() - t0, "ok" if traffic_probe else "unavailable"))
+
     import torch
     import dogeray_amd as dr
     from dogeray_amd import multigpu
 
     dist = None
     backend = os.environ.get("DOGERAY_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N > 1 path on a box with fewer GPUs than ranks
-    ndev = dr.device_count()
-    device_index = local_rank if backend == "nccl" else local_rank % max(1, ndev)
+    device_index = local_rank if backend == "nccl" else local_rank % max(1, torch.cuda.device_count())
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(device_index)
@@ -111,8 +166,6 @@ def main():
     mode = dr.TRAVERSAL_ORDERED if args.traversal == "ordered" else dr.TRAVERSAL_THREADED
     ctx.set_traversal(mode)
     ctx.set_stripe(world, rank)
-    if args.batch <= 0:
-        args.batch = max(32, 8 * world)
     if args.gather_every <= 0:
         args.gather_every = args.batch
     ctx.set_option("batch_frames", min(args.batch, 256))
@@ -239,6 +292,13 @@ def main():
         "simd_efficiency": {"node_loop": ref_order["node_visits"] / max(1, ref_order["trav_slots"]),
                             "bounce_loop": ref_order["rays"] / max(1, ref_order["ray_slots"])},
     }
+
+    if traffic_probe is not None:
+        t = traffic_probe
+        if t is not None:
+            result["roofline"]["traffic"] = t["bytes_per_launch"]
+            result["roofline"]["traffic_note"] = ("rocprofv3 PMC, separate passes, per launch of the timed kernel: 2 x FETCH_SIZE (%.3g B raw; gfx950 reports "
+                                                  "half of 16-B/lane reads) + WRITE_SIZE (%.3g B)" % (t["fetch_size_bytes_raw"], t["write_size_bytes"]))
 
     if world == 1 and not args.no_cpu_baseline:
         try:

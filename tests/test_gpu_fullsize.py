@@ -13,8 +13,29 @@ pytestmark = pytest.mark.gpu
 W, H = 1920, 1080
 
 
+OTHER_CONFIGS = [
+    ("C2 bunnyish 1280x720", ["bunnyish", "6", "1280", "720"], 1280, 720, False, 81922),
+    ("C5 city 3840x2160", ["city", "200", "3840", "2160"], 3840, 2160, False, 480002),
+    ("C3 textured 1920x1080", ["matball", "1920", "1080"], 1920, 1080, True, 87),
+]
+
+
 @pytest.fixture(scope="module")
-def big(tmp_path_factory):
+def other_scenes(tmp_path_factory, synth):
+    """The stand-in scenes of the other configs, generated before anything in this module touches the GPU."""
+    import subprocess
+    from conftest import SCENEGEN
+    d = tmp_path_factory.mktemp("configs")
+    paths = {}
+    for name, gen_args, *_ in OTHER_CONFIGS:
+        p = str(d / (gen_args[0] + ".rts"))
+        subprocess.check_call([SCENEGEN, gen_args[0], p] + gen_args[1:])
+        paths[name] = p
+    return paths
+
+
+@pytest.fixture(scope="module")
+def big(tmp_path_factory, other_scenes):
     import sys
     sys.path.insert(0, ROOT)
     import bench
@@ -109,18 +130,11 @@ def test_sampled_columns_match_the_oracle(big):
 
 
 # The other BASELINE.json configs at their full sizes (stand-ins per SURVEY 8(d)): parity-test cases, not bench lines.
-@pytest.mark.parametrize("name,gen_args,Wc,Hc,tex,tris", [
-    ("C2 bunnyish 1280x720", ["bunnyish", "6", "1280", "720"], 1280, 720, False, 81922),
-    ("C5 city 3840x2160", ["city", "200", "3840", "2160"], 3840, 2160, False, 480002),
-    ("C3 textured 1920x1080", ["matball", "1920", "1080"], 1920, 1080, True, 87),
-])
-def test_other_configs_full_size(tmp_path, synth, name, gen_args, Wc, Hc, tex, tris):
-    import subprocess
+@pytest.mark.parametrize("name,gen_args,Wc,Hc,tex,tris", OTHER_CONFIGS)
+def test_other_configs_full_size(other_scenes, synth, name, gen_args, Wc, Hc, tex, tris):
     import dogeray_amd as dr
-    from conftest import SCENEGEN
     from oracle import orc
-    path = str(tmp_path / "scene.rts")
-    subprocess.check_call([SCENEGEN, gen_args[0], path] + gen_args[1:])
+    path = other_scenes[name]
     texdir = synth["tex"] if tex else ""
     scene = dr.Scene.load(path, texdir)
     assert scene.num_objects == tris

@@ -29,7 +29,7 @@ def orc():
 
 
 @pytest.fixture(scope="module")
-def ctx(dr):
+def ctx(dr, synth):          # synth first: the generated scenes exist before this process touches the GPU
     c = dr.Context(0)
     yield c
     c.close()
