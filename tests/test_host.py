@@ -259,3 +259,23 @@ def test_fuzzed_scenes_parse_and_build_like_the_oracle(dr, orc, synth, tmp_path)
         assert ps.num_objects == os_.n == n
         assert_same_objects(ps, os_)
         assert_same_bvh(ps, os_)
+
+
+def test_rts_writer_round_trip(dr, synth, tmp_path):
+    """dogeray_amd.rts_io.write_rts -> Scene.load reproduces the scene (values that six decimals carry)."""
+    from dogeray_amd import rts_io
+    src = dr.Scene.load(os.path.join(synth["dir"], "matball.rts"), synth["tex"])
+    objs = src.objects()[:-1]
+    names = ["a.ppm", "bah.ppm", "env.ppm", "synth_albedo.ppm", "synth_env.ppm", "synth_rough.ppm", "testtwo.ppm"]   # sorted directory order
+    out = rts_io.write_rts(str(tmp_path / "rt.rts"), objs, src.settings(), texture_names=names)
+    assert rts_io.validate_rts(out) == []
+    back = dr.Scene.load(out, synth["tex"])
+    assert back.num_objects == src.num_objects
+    assert back.objects().tobytes() == src.objects().tobytes()       # the generator wrote %f too, so nothing is lost
+    assert bytes(back.settings()) == bytes(src.settings())
+    # shorter generations of the format keep the struct defaults for the missing columns
+    short = dr.Scene.load(rts_io.write_rts(str(tmp_path / "rt16.rts"), objs, None, ncols=16), "").objects()
+    assert np.array_equal(short["pos"], src.objects()["pos"]) and short["texnum"].max() == -1 and short["norm"][0].tolist() == [-2, -3, -20]
+    bad = tmp_path / "bad.rts"
+    bad.write_text("1,2,x,2,0.5\n")
+    assert len(rts_io.validate_rts(str(bad))) == 2
