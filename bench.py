@@ -102,7 +102,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--traversal", choices=["threaded", "ordered"], default="threaded")
-    ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch (default max(32, 8 x GPUs): a launch has to outlast its longest pixel, ~3 ms)")
+    ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch (default 32 x GPUs, at most 256: a launch has to outlast its longest pixel, ~3 ms)")
     ap.add_argument("--gather-every", type=int, default=0, help="frames between two gathers to rank 0 (default: --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
@@ -120,7 +120,7 @@ def main():
         args.gpus = world
 
     if args.batch <= 0:
-        args.batch = max(32, 8 * world)
+        args.batch = min(256, 32 * world)     # constant work per launch and GPU: a launch has to outlast its longest pixel (~3 ms)
     # HBM traffic of the timed kernel: rocprofv3 PMC passes over child runs of this same command.  Done first,
     # before this process touches the GPU (a process that has initialised HIP should not spawn programs).
     traffic_probe = None
@@ -177,6 +177,9 @@ def main():
     ctx.accum_reset(W, H)
     acc = multigpu.accumulator_tensor(ctx, torch.device("cuda", device_index)) if world > 1 else None
     coll_dev = "cuda" if backend == "nccl" else "cpu"
+    gatherer = None
+    if world > 1:
+        gatherer = multigpu.FrameGatherer(acc if backend == "nccl" else acc.cpu(), W, H, world, rank)
 
     def run_frames(first, count):
         """Render frames [first, first+count) into the accumulator; gather every --gather-every frames."""
@@ -185,7 +188,7 @@ def main():
             n = min(args.gather_every, count - k) if world > 1 else count - k
             ctx.render_accumulate(st, W, H, s.background, seed_base + (first + k) * seed_stride, seed_stride, n)
             if world > 1:
-                multigpu.gather_frame(acc if backend == "nccl" else acc.cpu(), W, H, world, rank)
+                gatherer.gather(acc if backend == "nccl" else acc.cpu())
                 torch.cuda.synchronize()      # the gather reads the accumulator on torch's stream: finish before the next frames write it
             k += n
 

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       // already old is finished by the whole wave at once (coop_closest_hit) instead of holding the launch
       // open for hundreds of further dependent steps.  (The counting build keeps the plain walk so that
       // its counters stay those of the reference order.)
-      unsigned long long cand = __ballot(tr.node >= 0 && !(PARK_MIN > 0 && pk.parked) && steps - rstart >= (unsigned)P.coop_steps);
+      unsigned long long cand = __ballot(tr.node >= 0 && !(PARK_MIN > 0 && pk.parked) && (int)(steps - rstart) >= P.coop_steps);
       while (cand != 0ull) {
         const int L = __ffsll((long long)cand) - 1;
         cand &= cand - 1ull;
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
                                            my_lds, r);
         if (lane == L) {
           if (done) { tr.best_t = r.t; tr.best_slot = r.slot; tr.node = -1; }
-          else rstart = 0x80000000u;              // stack overflow: never ask again for this ray (steps - rstart wraps below the threshold)
+          else rstart = 0x80000000u;              // stack overflow: never ask again for this ray ((int)(steps - rstart) is negative from now on)
         }
       }
     }

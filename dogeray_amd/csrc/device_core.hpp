@@ -304,8 +304,8 @@ __device__ __forceinline__ bool coop_closest_hit(const DevPair* __restrict__ pai
       float mn0[3] = {A.x, A.y, A.z}, mx0[3] = {B.x, B.y, B.z};
       float mn1[3] = {C.x, C.y, C.z}, mx1[3] = {D.x, D.y, D.z};
       float d0, d1;
-      const bool h0 = slab(o, inv, mn0, mx0, d0) && d0 < prune_t;
-      const bool h1 = slab(o, inv, mn1, mx1, d1) && d1 < prune_t;
+      const bool h0 = slab(o, inv, mn0, mx0, d0) && d0 <= prune_t;   // <=: a box entered exactly at the best t may hold a tie with a lower slot
+      const bool h1 = slab(o, inv, mn1, mx1, d1) && d1 <= prune_t;
       if (h0 && c0 < 0) {
         const int slot = ~c0;
         float t = prim_hit(prims, slot, o, d);
@@ -390,8 +390,8 @@ __device__ __forceinline__ Hit closest_hit_ordered(const DevPair* __restrict__ p
     float mn1[3] = {C.x, C.y, C.z}, mx1[3] = {D.x, D.y, D.z};
     float d0, d1;
     if (COUNT) c.V += 2;
-    bool h0 = slab(o, inv, mn0, mx0, d0) && d0 < best.t;
-    bool h1 = slab(o, inv, mn1, mx1, d1) && d1 < best.t;
+    bool h0 = slab(o, inv, mn0, mx0, d0) && d0 <= best.t;     // <=: a box entered exactly at the best t may hold a tie with a lower slot
+    bool h1 = slab(o, inv, mn1, mx1, d1) && d1 <= best.t;
     if (h0 && c0 < 0) {
       int slot = ~c0;
       if (COUNT) c.L++;
@@ -400,7 +400,7 @@ __device__ __forceinline__ Hit closest_hit_ordered(const DevPair* __restrict__ p
       h0 = false;
     }
     if (h1 && c1 < 0) {
-      if (d1 < best.t) {
+      if (d1 <= best.t) {
         int slot = ~c1;
         if (COUNT) c.L++;
         float t = prim_hit(prims, slot, o, d);
@@ -408,8 +408,8 @@ __device__ __forceinline__ Hit closest_hit_ordered(const DevPair* __restrict__ p
       }
       h1 = false;
     }
-    h0 = h0 && d0 < best.t;
-    h1 = h1 && d1 < best.t;
+    h0 = h0 && d0 <= best.t;
+    h1 = h1 && d1 <= best.t;
     if (h0 && h1) {
       bool first0 = d0 <= d1;
       int far_c = first0 ? c1 : c0;

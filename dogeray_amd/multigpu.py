@@ -33,31 +33,42 @@ def accumulator_tensor(ctx, device):
     return torch.as_tensor(_DevArray(ptr, nbytes // 4), device=device)
 
 
+class FrameGatherer:
+    """gather_frame with its buffers allocated once (the bench gathers after every launch: at 8 ranks a
+    launch lasts a few ms, so 25 MB of fresh zero-filled buffers per gather would show)."""
+
+    def __init__(self, acc, W, H, world, rank, group=None):
+        import torch
+        self.W, self.H, self.world, self.rank, self.group = W, H, world, rank, group
+        self.gx = W // 8
+        self.run = 8 * H * 3
+        self.per = (self.gx + world - 1) // world           # ranks own per or per-1 columns
+        self.pack = torch.zeros((self.per, self.run), dtype=acc.dtype, device=acc.device)
+        self.parts = [torch.empty_like(self.pack) for _ in range(world)] if rank == 0 and world > 1 else None
+        self.full = torch.zeros_like(acc) if rank == 0 and world > 1 else None
+
+    def gather(self, acc):
+        import torch.distributed as dist
+        if self.world == 1:
+            return acc
+        cols = acc[: self.gx * self.run].view(self.gx, self.run)
+        mine = cols[self.rank::self.world]
+        self.pack[: mine.shape[0]] = mine
+        if self.rank != 0:
+            dist.gather(self.pack, gather_list=None, dst=0, group=self.group)
+            return None
+        dist.gather(self.pack, gather_list=self.parts, dst=0, group=self.group)
+        fcols = self.full[: self.gx * self.run].view(self.gx, self.run)
+        for r in range(self.world):
+            n = len(range(r, self.gx, self.world))
+            fcols[r::self.world] = self.parts[r][:n]
+        return self.full
+
+
 def gather_frame(acc, W, H, world, rank, group=None):
     """acc: this rank's int32[W*H*3] accumulator (zeros outside its block columns).
     Returns the assembled int32[W*H*3] frame on rank 0, None elsewhere."""
-    import torch
-    import torch.distributed as dist
-    gx = W // 8
-    run = 8 * H * 3
-    cols = acc[: gx * run].view(gx, run)
-    if world == 1:
-        return acc
-    per = (gx + world - 1) // world                     # ranks own per or per-1 columns
-    mine = cols[rank::world]
-    pack = torch.zeros((per, run), dtype=acc.dtype, device=acc.device)
-    pack[: mine.shape[0]] = mine
-    if rank == 0:
-        parts = [torch.empty_like(pack) for _ in range(world)]
-        dist.gather(pack, gather_list=parts, dst=0, group=group)
-        full = torch.zeros_like(acc)
-        fcols = full[: gx * run].view(gx, run)
-        for r in range(world):
-            n = len(range(r, gx, world))
-            fcols[r::world] = parts[r][:n]
-        return full
-    dist.gather(pack, gather_list=None, dst=0, group=group)
-    return None
+    return FrameGatherer(acc, W, H, world, rank, group).gather(acc)
 
 
 def gather_frame_numpy(acc_np, W, H, world, rank, group=None):

@@ -3,7 +3,7 @@
 VARS=$1; shift
 mkdir -p gpurun_out
 for v in $VARS; do
-  DOGERAY_OPTIONS=$v python3 bench.py --steps 16 --warmup 2 --no-cpu-baseline "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
+  DOGERAY_OPTIONS=$v python3 bench.py --steps ${STEPS:-16} --warmup ${WARM:-2} --no-cpu-baseline --no-traffic "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
   python3 - <<PY
 import json
 j=json.loads(open("gpurun_out/ab_$v.json").read().strip().splitlines()[-1])
