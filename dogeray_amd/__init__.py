@@ -23,6 +23,7 @@ TRAVERSAL_THREADED = 0
 TRAVERSAL_ORDERED = 1
 KERNEL_TILE = 0
 KERNEL_PERSISTENT = 1
+ERR_INVALID, ERR_IO, ERR_PARSE, ERR_SCENE, ERR_DEVICE, ERR_NOMEM = -1, -2, -3, -4, -5, -6      # enum dr_status
 
 
 class DogerayError(RuntimeError):
@@ -84,6 +85,8 @@ _API = [
     ("dr_scene_bvh_size", C.c_int, [_VP]),
     ("dr_scene_bvh_used", C.c_int, [_VP]),
     ("dr_scene_get_bvh", C.c_int, [_VP, _VP]),
+    ("dr_scene_save_binary", C.c_int, [_VP, C.c_char_p]),
+    ("dr_scene_load_binary", C.c_int, [C.c_char_p, C.POINTER(_VP)]),
     ("dr_device_count", C.c_int, []),
     ("dr_context_create", C.c_int, [C.c_int, C.POINTER(_VP)]),
     ("dr_context_destroy", None, [_VP]),
@@ -173,6 +176,17 @@ class Scene:
         td = None if texture_dir is None else os.fsencode(texture_dir)
         _check(lib().dr_scene_load(os.fsencode(rts_path), td, C.byref(h)))
         return cls(h)
+
+    @classmethod
+    def load_binary(cls, rtsb_path):
+        """A scene saved with save_binary(): objects, settings, textures and (if it was built) the BVH."""
+        h = _VP()
+        _check(lib().dr_scene_load_binary(os.fsencode(rtsb_path), C.byref(h)))
+        return cls(h)
+
+    def save_binary(self, rtsb_path):
+        _check(lib().dr_scene_save_binary(self._h, os.fsencode(rtsb_path)))
+        return rtsb_path
 
     @classmethod
     def from_arrays(cls, objects, settings=None, bvh=None, textures=()):

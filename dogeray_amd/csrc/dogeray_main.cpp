@@ -15,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <sys/stat.h>
 
 #include "../../include/dogeray_amd.h"
 
@@ -69,11 +70,13 @@ bool write_bmp(const std::string& path, const std::vector<uint8_t>& rgb, int W, 
 void usage() {
   fprintf(stderr,
           "usage: dogeray [scene.rts] [--textures DIR] [--frames N] [--out FILE.bmp|.ppm] [--width W] [--height H]\n"
-          "               [--spp S] [--depth D] [--seed N] [--device I] [--group G] [--quiet]\n"
+          "               [--spp S] [--depth D] [--seed N] [--device I] [--group G] [--cache] [--quiet]\n"
           "  scene        .rts file (default scene.rts, as the reference)\n"
           "  --textures   directory scanned for *ppm* textures (default: current directory, as the reference)\n"
           "  --frames     full-resolution frames to accumulate after the 4 preview stages (default 64)\n"
-          "  --group      frames rendered between two presents once accumulating (default 8)\n");
+          "  --group      frames rendered between two presents once accumulating (default 8)\n"
+          "  --cache      keep a binary image of the parsed scene + BVH next to the scene (scene.rtsb) and start from\n"
+          "               it while it is newer than the .rts ('r' fields and textures are frozen in it: delete it to redraw)\n");
 }
 
 }  // namespace
@@ -83,7 +86,7 @@ int main(int argc, char** argv) {
   const char* texdir = nullptr;
   int frames = 64, device = 0, group = 8, width = 0, height = 0, spp = 0, depth = 0;
   uint64_t seed = 1;
-  bool quiet = false, have_scene = false;
+  bool quiet = false, have_scene = false, use_cache = false;
   for (int i = 1; i < argc; i++) {
     std::string a = argv[i];
     auto next = [&]() -> const char* { if (i + 1 >= argc) { usage(); exit(2); } return argv[++i]; };
@@ -98,6 +101,7 @@ int main(int argc, char** argv) {
     else if (a == "--device") device = atoi(next());
     else if (a == "--group") group = atoi(next());
     else if (a == "--quiet") quiet = true;
+    else if (a == "--cache") use_cache = true;
     else if (a == "-h" || a == "--help") { usage(); return 0; }
     else if (!have_scene && a[0] != '-') { scene_path = a; have_scene = true; }
     else { usage(); return 2; }
@@ -107,7 +111,17 @@ int main(int argc, char** argv) {
   if (!quiet) printf("DOGERAY render path on MI355X (dogeray_amd, C ABI v%d)\n", dr_abi_version());
   printf("%s%s\n", have_scene ? "Opening:" : "Opening Default Scene: ", scene_path.c_str());   // K:2045-2050
   dr_scene* scene = nullptr;
-  if (dr_scene_load(scene_path.c_str(), texdir, &scene) != DR_OK) die("cannot load scene");
+  const std::string cache_path = scene_path + "b";           // x.rts -> x.rtsb
+  bool from_cache = false;
+  if (use_cache) {
+    struct stat st_rts, st_bin;
+    if (stat(scene_path.c_str(), &st_rts) == 0 && stat(cache_path.c_str(), &st_bin) == 0 && st_bin.st_mtime >= st_rts.st_mtime) {
+      if (dr_scene_load_binary(cache_path.c_str(), &scene) == DR_OK) from_cache = true;
+      else fprintf(stderr, "ignoring %s: %s\n", cache_path.c_str(), dr_last_error());
+    }
+  }
+  if (!from_cache && dr_scene_load(scene_path.c_str(), texdir, &scene) != DR_OK) die("cannot load scene");
+  if (from_cache && !quiet) printf("(scene taken from %s)\n", cache_path.c_str());
   printf("%d tris\n%d textures total\n", dr_scene_num_objects(scene) + 1, dr_scene_num_textures(scene));   // K:2056,1995 (objnum = count + 1)
   dr_settings s;
   dr_scene_get_settings(scene, &s);
@@ -117,7 +131,8 @@ int main(int argc, char** argv) {
   if (depth > 0) s.max_depth = depth;
   printf("Building BVH..\n");
   auto t0 = std::chrono::steady_clock::now();
-  if (dr_scene_build_bvh(scene, 0) != DR_OK) die("cannot build the BVH");
+  if (dr_scene_bvh_size(scene) == 0 && dr_scene_build_bvh(scene, 0) != DR_OK) die("cannot build the BVH");
+  if (use_cache && !from_cache && dr_scene_save_binary(scene, cache_path.c_str()) != DR_OK) fprintf(stderr, "cannot write %s: %s\n", cache_path.c_str(), dr_last_error());
   double bvh_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   printf("Done!\n%d nodes total (%.0f ms)\n", dr_scene_bvh_size(scene), bvh_ms);               // K:2093-2094
 

@@ -117,6 +117,13 @@ int dr_scene_bvh_size(const dr_scene* s);                /* bvhnum = 2 * (N + 1)
 int dr_scene_bvh_used(const dr_scene* s);                /* actualbvhnum = 2N - 1          */
 int dr_scene_get_bvh(const dr_scene* s, dr_bvh_node* out /* dr_scene_bvh_size entries */);
 
+/* .rtsb sidecar: binary image of a loaded scene -- objects as parsed ('r' fields frozen at
+ * the values this load drew), settings, decoded textures and, if built, the BVH -- so that a second start-up
+ * skips getnum/read/build_bvh (K:2055-2094: 330 MB of text at 1M triangles).  The file carries the record sizes
+ * of this ABI and a checksum; anything that does not match is DR_ERR_PARSE, never a partly filled scene. */
+int dr_scene_save_binary(const dr_scene* s, const char* rtsb_path);
+int dr_scene_load_binary(const char* rtsb_path, dr_scene** out);
+
 /* ------------------------------------------------------------------ device -------------- */
 
 int dr_device_count(void);

@@ -247,6 +247,23 @@ def test_host_application_reports_missing_gpu_or_renders(tmp_path):
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
 
 
+def test_host_application_cache(tmp_path, dr):
+    """dogeray --cache writes scene.rtsb after the build and starts from it the second time (same object/node report)."""
+    import shutil
+    exe = os.path.join(ROOT, "dogeray_amd", "bin", "dogeray")
+    scene = shutil.copy(os.path.join(SCENES, "cube.rts"), str(tmp_path / "cube.rts"))
+    cmd = [exe, scene, "--textures", "", "--frames", "1", "--width", "64", "--height", "64", "--cache"]
+    first = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert os.path.exists(scene + "b") and "taken from" not in first.stdout
+    cached = dr.Scene.load_binary(scene + "b")
+    fresh = dr.Scene.load(scene, "")
+    fresh.build_bvh()
+    assert cached.bvh()[0].tobytes() == fresh.bvh()[0].tobytes() and cached.objects().tobytes() == fresh.objects().tobytes()
+    second = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert "taken from" in second.stdout and "97 tris" in second.stdout and "194 nodes total" in second.stdout
+    assert first.returncode == second.returncode
+
+
 def test_fuzzed_scenes_parse_and_build_like_the_oracle(dr, orc, synth, tmp_path):
     """Random scenes (mixed column counts, spheres, duplicates, degenerate triangles): objects and BVH identical."""
     from scene_fuzz import random_scene
@@ -279,3 +296,32 @@ def test_rts_writer_round_trip(dr, synth, tmp_path):
     bad = tmp_path / "bad.rts"
     bad.write_text("1,2,x,2,0.5\n")
     assert len(rts_io.validate_rts(str(bad))) == 2
+
+
+def test_rtsb_round_trip(dr, synth, tmp_path):
+    """.rtsb sidecar: the reloaded scene is the loaded + built scene byte for byte; damaged files are refused."""
+    src = dr.Scene.load(os.path.join(synth["dir"], "matball.rts"), synth["tex"])
+    unbuilt = dr.Scene.load_binary(src.save_binary(str(tmp_path / "unbuilt.rtsb")))
+    assert unbuilt.bvh()[0].size == 0 and unbuilt.objects().tobytes() == src.objects().tobytes()
+    src.build_bvh()
+    path = src.save_binary(str(tmp_path / "m.rtsb"))
+    back = dr.Scene.load_binary(path)
+    assert back.num_objects == src.num_objects
+    assert back.objects().tobytes() == src.objects().tobytes()
+    assert bytes(back.settings()) == bytes(src.settings())
+    assert back.bvh()[1] == src.bvh()[1] and back.bvh()[0].tobytes() == src.bvh()[0].tobytes()
+    assert len(back.textures()) == len(src.textures()) > 0
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(back.textures(), src.textures()))
+    unbuilt.build_bvh()                                   # a cache saved before the build builds the same tree
+    assert unbuilt.bvh()[0].tobytes() == src.bvh()[0].tobytes()
+    raw = open(path, "rb").read()
+    cases = {"flip": raw[:5000] + bytes([raw[5000] ^ 1]) + raw[5001:], "cut": raw[:-7], "long": raw + b"x", "magic": b"X" + raw[1:], "empty": b""}
+    for name, data in cases.items():
+        p = tmp_path / (name + ".rtsb")
+        p.write_bytes(data)
+        with pytest.raises(dr.DogerayError) as e:
+            dr.Scene.load_binary(str(p))
+        assert e.value.code == dr.ERR_PARSE, name
+    with pytest.raises(dr.DogerayError) as e:
+        dr.Scene.load_binary(str(tmp_path / "missing.rtsb"))
+    assert e.value.code == dr.ERR_IO
