@@ -42,7 +42,8 @@ def build(force=False, verbose=False):
         if force or _stale(obj, [sp] + headers + [os.path.abspath(__file__)]):
             # -fno-slp-vectorize: hipcc otherwise packs adjacent scalar f32 ops into v_pk_* instructions, which
             # issue slower than the scalars they replace on gfx950 (measured: +4.6 % rays/s without them)
-            cmd = [hipcc] + COMMON + ["-fno-slp-vectorize", "--offload-arch=" + ARCH, "-c", sp, "-o", obj]
+            slp = [] if os.environ.get("DOGERAY_SLP") == "1" else ["-fno-slp-vectorize"]      # DOGERAY_SLP=1: experiment knob
+            cmd = [hipcc] + COMMON + slp + ["--offload-arch=" + ARCH, "-c", sp, "-o", obj]
             if src.endswith(".cpp"):
                 cmd = [hipcc] + COMMON + ["-x", "c++", "-c", sp, "-o", obj]
             if verbose:

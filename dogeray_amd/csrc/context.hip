@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   // diagnostic stamps (counting build only): wave lifetime, cycles inside the shade/refill phase
   unsigned long long t_begin = 0, t_phase = 0, n_iter = 0, n_phase = 0;
   if (COUNT) t_begin = __builtin_readcyclecounter();
-  ParkedLeaf pk; pk.v0x = 0; pk.C = pk.D = make_float4(0, 0, 0, 0); pk.info = 0; pk.parked = false;   // PARK_MIN > 0 only
+  ParkedLeaf pk; pk.v0x = 0; pk.C = pk.D = u32x4{0, 0, 0, 0}; pk.info = 0; pk.parked = false;   // PARK_MIN > 0 only
   for (;;) {
     const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;
@@ -124,8 +124,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
       float* const st = reinterpret_cast<float*>(my_lds) + lane;      // slot k of this lane: st[k * 64]
       {
-        st[0 * 64] = pk.v0x; st[1 * 64] = pk.C.x; st[2 * 64] = pk.C.y; st[3 * 64] = pk.C.z; st[4 * 64] = pk.C.w;
-        st[5 * 64] = pk.D.x; st[6 * 64] = pk.D.y; st[7 * 64] = pk.D.z; st[8 * 64] = pk.D.w;
+        st[0 * 64] = pk.v0x; st[1 * 64] = __uint_as_float(pk.C.x); st[2 * 64] = __uint_as_float(pk.C.y); st[3 * 64] = __uint_as_float(pk.C.z); st[4 * 64] = __uint_as_float(pk.C.w);
+        st[5 * 64] = __uint_as_float(pk.D.x); st[6 * 64] = __uint_as_float(pk.D.y); st[7 * 64] = __uint_as_float(pk.D.z); st[8 * 64] = __uint_as_float(pk.D.w);
         st[9 * 64] = __int_as_float(pk.info); st[10 * 64] = pk.parked ? 1.0f : 0.0f;
         st[11 * 64] = inv.x; st[12 * 64] = inv.y; st[13 * 64] = inv.z;
         // pixel bookkeeping: not needed while the hit is shaded, back right after
@@ -244,8 +244,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
       {
         asm volatile("" ::: "memory");
-        pk.v0x = st[0 * 64]; pk.C = make_float4(st[1 * 64], st[2 * 64], st[3 * 64], st[4 * 64]);
-        pk.D = make_float4(st[5 * 64], st[6 * 64], st[7 * 64], st[8 * 64]);
+        pk.v0x = st[0 * 64]; pk.C = u32x4{__float_as_uint(st[1 * 64]), __float_as_uint(st[2 * 64]), __float_as_uint(st[3 * 64]), __float_as_uint(st[4 * 64])};
+        pk.D = u32x4{__float_as_uint(st[5 * 64]), __float_as_uint(st[6 * 64]), __float_as_uint(st[7 * 64]), __float_as_uint(st[8 * 64])};
         pk.info = __float_as_int(st[9 * 64]); pk.parked = st[10 * 64] != 0.0f;
         inv = mk(st[11 * 64], st[12 * 64], st[13 * 64]);
         if (fresh_ray) inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);

@@ -164,10 +164,16 @@ __device__ __forceinline__ float prim_hit_kind(int kind, V3 v0, V3 e1, V3 e2, V3
   if (dist < 10000.0f && dist > -0.0f) return dist;          // K:449
   return -1.0f;
 }
-// successor of a leaf record at byte offset `off`: the next record (4 units on), or the end of the walk
-__device__ __forceinline__ int leaf_successor(unsigned off, int info) {
-  const int next = (int)(((off >> 4) + WALK_UNITS_LEAF) << 1) | ((info >> 28) & 1);
-  return (info >> 29) & 1 ? -1 : next;
+// successor of the leaf record that link `node` (bit 0 set) points to: the next record (4 units on), or the end
+// of the walk.  The walk array ends with a terminator record (an internal node with an empty box and both links
+// -1), so the plain build needs no end test: the last leaf's successor is that record (two instructions instead
+// of eight on the hot path).  The counting build stops at the last leaf itself so that its visit counter stays
+// the reference's.
+template <bool COUNT>
+__device__ __forceinline__ int leaf_successor(int node, int info) {
+  const int next = node + (2 * WALK_UNITS_LEAF - 1) + ((info >> 28) & 1);
+  if (COUNT) return (info >> 29) & 1 ? -1 : next;
+  return next;
 }
 __device__ __forceinline__ float prim_hit(const DevPrim* __restrict__ prims, int slot, V3 o, V3 d) {
   const float4* p = reinterpret_cast<const float4*>(prims + slot);
@@ -211,7 +217,7 @@ __device__ __forceinline__ void trav_step(WalkRsrc walk, V3 o, V3 d, V3 inv, Tra
   if (leaf) { C = ld_unit(walk, off + 32); D = ld_unit(walk, off + 48); }
   float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
   const int w0 = __float_as_int(A.w);
-  const int next_miss = leaf ? leaf_successor(off, w0) : __float_as_int(B.w);
+  const int next_miss = leaf ? leaf_successor<COUNT>(tr.node, w0) : __float_as_int(B.w);
   float dist;
   if (COUNT) c.V++;
   bool h = slab(o, inv, mn, mx, dist);
@@ -233,7 +239,10 @@ __device__ __forceinline__ void trav_step(WalkRsrc walk, V3 o, V3 d, V3 inv, Tra
 // it has just fetched and waits ("parks") until enough lanes of the wave have one, so the
 // ~90-instruction triangle test runs once for many lanes instead of on nearly every iteration for
 // one or two.  The per-lane sequence of tests and updates is unchanged.
-struct ParkedLeaf { float v0x; float4 C, D; int info; bool parked; };
+// C and D stay 128-bit register tuples from the load to the test (as scalars the allocator scattered them and
+// copied all eight back and forth on every step).
+struct ParkedLeaf { float v0x; u32x4 C, D; int info; bool parked; };
+__device__ __forceinline__ u32x4 ld_unit_raw(WalkRsrc r, unsigned byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0); }
 
 template <bool COUNT>
 __device__ __forceinline__ void trav_step_park(WalkRsrc walk, V3 o, V3 inv, Trav& tr, ParkedLeaf& pk, Ctr& c) {
@@ -241,10 +250,10 @@ __device__ __forceinline__ void trav_step_park(WalkRsrc walk, V3 o, V3 inv, Trav
   const unsigned off = (unsigned)(tr.node >> 1) << 4;
   float4 A = ld_unit(walk, off), B = ld_unit(walk, off + 16);
   // a stepping lane is not parked, so its parked record is free: the leaf's primitive lands there directly
-  if (leaf) { pk.C = ld_unit(walk, off + 32); pk.D = ld_unit(walk, off + 48); }
+  if (leaf) { pk.C = ld_unit_raw(walk, off + 32); pk.D = ld_unit_raw(walk, off + 48); }
   float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
   const int w0 = __float_as_int(A.w);
-  const int next_miss = leaf ? leaf_successor(off, w0) : __float_as_int(B.w);
+  const int next_miss = leaf ? leaf_successor<COUNT>(tr.node, w0) : __float_as_int(B.w);
   float dist;
   if (COUNT) c.V++;
   bool h = slab(o, inv, mn, mx, dist) && dist < tr.best_t;
@@ -255,7 +264,8 @@ __device__ __forceinline__ void trav_step_park(WalkRsrc walk, V3 o, V3 inv, Trav
 template <bool COUNT>
 __device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk, Ctr& c) {
   if (COUNT) c.L++;
-  float t = prim_hit_kind((pk.info >> WALK_SLOT_BITS) & 3, mk(pk.v0x, pk.C.x, pk.C.y), mk(pk.C.z, pk.C.w, pk.D.x), mk(pk.D.y, pk.D.z, pk.D.w), o, d);
+  auto f = [](unsigned v) { return __uint_as_float(v); };
+  float t = prim_hit_kind((pk.info >> WALK_SLOT_BITS) & 3, mk(pk.v0x, f(pk.C.x), f(pk.C.y)), mk(f(pk.C.z), f(pk.C.w), f(pk.D.x)), mk(f(pk.D.y), f(pk.D.z), f(pk.D.w)), o, d);
   if (t > -0.01f && t < tr.best_t) { tr.best_t = t; tr.best_slot = pk.info & ((1 << WALK_SLOT_BITS) - 1); }   // K:488
   pk.parked = false;
 }

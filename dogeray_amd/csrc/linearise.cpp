@@ -124,12 +124,20 @@ int linearise(const HostScene& sc, DeviceImage& img) {
     std::vector<int64_t> unit_of((size_t)used + 1, 0);
     for (int k = 0; k < used; k++)
       unit_of[(size_t)k + 1] = unit_of[(size_t)k] + (sc.bvh[(size_t)order[(size_t)k]].end ? WALK_UNITS_LEAF : WALK_UNITS_INTERNAL);
-    if (unit_of[(size_t)used] >= ((int64_t)1 << 28)) { set_error("scene too large: the walk array must stay below 4 GiB (32-bit buffer offsets)"); return DR_ERR_SCENE; }
+    if (unit_of[(size_t)used] + WALK_UNITS_INTERNAL >= ((int64_t)1 << 28)) { set_error("scene too large: the walk array must stay below 4 GiB (32-bit buffer offsets)"); return DR_ERR_SCENE; }
     auto link_to = [&](int pre) -> int32_t {
       if (pre < 0) return -1;
       return (int32_t)((unit_of[(size_t)pre] << 1) | (sc.bvh[(size_t)order[(size_t)pre]].end ? 1 : 0));
     };
-    img.walk.assign((size_t)unit_of[(size_t)used], DevUnit());
+    img.walk.assign((size_t)unit_of[(size_t)used] + WALK_UNITS_INTERNAL, DevUnit());
+    {
+      // terminator: an internal record no ray enters (min > max), both links -1.  The last leaf's successor is
+      // "the next record" like every other leaf's, so the kernel's step needs no end-of-walk test.
+      DevUnit* t = &img.walk[(size_t)unit_of[(size_t)used]];
+      const int32_t end = -1;
+      for (int a = 0; a < 3; a++) { t[0].f[a] = 3.0e38f; t[1].f[a] = -3.0e38f; }
+      memcpy(&t[0].f[3], &end, 4); memcpy(&t[1].f[3], &end, 4);
+    }
     if (N > (1 << WALK_SLOT_BITS)) { set_error("scene too large for the walk array's slot field"); return DR_ERR_SCENE; }
     for (int k = 0; k < used; k++) {
       const dr_bvh_node& b = sc.bvh[(size_t)order[(size_t)k]];
