@@ -173,7 +173,7 @@ int build_bvh(HostScene& sc, int nthreads) {
     return DR_ERR_SCENE;
   }
   if ((int)sc.objects.size() != N + 1) { set_error("scene object array has the wrong size"); return DR_ERR_INVALID; }
-  if (nthreads <= 0) nthreads = (int)std::thread::hardware_concurrency();
+  if (nthreads <= 0) nthreads = usable_threads();
   if (nthreads < 1) nthreads = 1;
 
   Builder b(sc);

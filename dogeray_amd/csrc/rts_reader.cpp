@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dirent.h>
+#include <sched.h>
 #include <thread>
 #include <unistd.h>
 #include <utility>
@@ -36,6 +37,26 @@ dr_object default_object() {
   o.t3[0] = 1; o.t3[1] = 0;
   o.texnum = -1; o.rtexnum = -1;                           // K:70-71
   return o;
+}
+
+int usable_threads() {
+  long n = 0;
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = CPU_COUNT(&set);
+  if (n <= 0) n = (long)std::thread::hardware_concurrency();
+  // cgroup v2 quota ("<quota> <period>" or "max <period>"): a container may see every CPU of the host and own a few
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    char q[32] = {0};
+    long period = 0;
+    if (fscanf(f, "%31s %ld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+      long lim = (atol(q) + period / 2) / period;
+      if (lim >= 1 && lim < n) n = lim;
+    }
+    fclose(f);
+  }
+  if (n < 1) n = 1;
+  if (n > 256) n = 256;
+  return (int)n;
 }
 
 dr_settings default_settings() {
@@ -314,8 +335,7 @@ int read_rts(const char* path, HostScene& sc) {
     std::vector<long> settings_line;
     bool failed = false; long err_line = 0; std::string err;
   };
-  unsigned nthreads = std::thread::hardware_concurrency();
-  if (nthreads == 0) nthreads = 1;
+  unsigned nthreads = (unsigned)usable_threads();
   size_t want = data.size() / (1 << 20) + 1;              // at least ~1 MB per piece
   if (want < nthreads) nthreads = (unsigned)want;
   std::vector<Piece> pieces(nthreads);

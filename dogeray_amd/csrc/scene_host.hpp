@@ -27,6 +27,7 @@ struct HostScene {
 void set_error(const std::string& msg);
 const std::string& get_error();
 
+int usable_threads();           // CPUs this process may use: affinity mask capped by the cgroup CPU quota
 dr_object default_object();    // struct defaults K:55-71, everything else 0
 dr_settings default_settings();  // K:29-30,109,123-132
 
