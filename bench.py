@@ -182,6 +182,7 @@ def main():
     if dist is not None:
         dist.barrier()
     scene_path = ensure_scene(args.cache, args.verts, W, H)
+    t0 = time.time()
     scene = dr.Scene.load(scene_path, "")
     t_parse = time.time() - t0
     t0 = time.time()
