@@ -94,6 +94,7 @@ _API = [
     ("dr_context_set_stripe", C.c_int, [_VP, C.c_int, C.c_int]),
     ("dr_context_set_traversal", C.c_int, [_VP, C.c_int]),
     ("dr_context_set_option", C.c_int, [_VP, C.c_char_p, C.c_int]),
+    ("dr_context_get_option", C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int)]),
     ("dr_render_frame", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, _VP]),
     ("dr_accum_reset", C.c_int, [_VP, C.c_int, C.c_int]),
     ("dr_render_accumulate", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_int]),
@@ -288,6 +289,11 @@ class Context:
     def set_option(self, name, value):
         """Tuning knob ("kernel", "batch_frames", "feedback", "occupancy", "trav_min", "park_min"); never changes a pixel."""
         _check(lib().dr_context_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int()
+        _check(lib().dr_context_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
 
     def render_frame(self, settings13, W, H, background, frame_seed, download=True):
         """Returns int32[W, H, 3] indexed [x, y] (the reference's column-major int3 buffer) or None."""

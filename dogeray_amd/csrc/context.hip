@@ -852,6 +852,25 @@ int dr_context_set_option(dr_context* c, const char* name, int value) {
   return set_option(c, name, value);
 }
 
+int dr_context_get_option(const dr_context* c, const char* name, int* value) {
+  if (!c || !name || !value) { set_error("null argument"); return DR_ERR_INVALID; }
+  const std::string n = name;
+  if (n == "kernel") *value = c->kernel;
+  else if (n == "batch_frames") *value = c->batch_frames;
+  else if (n == "feedback") *value = c->feedback ? 1 : 0;
+  else if (n == "occupancy") *value = c->occupancy;
+  else if (n == "trav_min") *value = c->trav_min;
+  else if (n == "park_min") *value = c->park_min;
+  else if (n == "unroll") *value = c->unroll;
+  else if (n == "xcd_regions") *value = c->xcd_regions;
+  else if (n == "heavy_factor") *value = c->heavy_factor;
+  else if (n == "coop_steps") *value = c->coop_steps;
+  else if (n == "coop_lanes") *value = c->coop_lanes;
+  else if (n == "tree_depth") *value = c->tree_depth;
+  else { set_error("unknown option " + n); return DR_ERR_INVALID; }
+  return DR_OK;
+}
+
 int dr_context_set_traversal(dr_context* c, int mode) {
   if (!c || (mode != DR_TRAVERSAL_THREADED && mode != DR_TRAVERSAL_ORDERED)) { set_error("unknown traversal mode"); return DR_ERR_INVALID; }
   if (mode == DR_TRAVERSAL_ORDERED && c->walk && c->tree_depth > ORDERED_STACK) {

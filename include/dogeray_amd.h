@@ -160,6 +160,8 @@ int dr_context_set_traversal(dr_context* c, int mode);
  * The environment variable DOGERAY_OPTIONS="name=value,..." applies the same at context creation. */
 enum { DR_KERNEL_TILE = 0, DR_KERNEL_PERSISTENT = 1 };
 int dr_context_set_option(dr_context* c, const char* name, int value);
+/* Read a knob back (same names), or "tree_depth" of the uploaded scene. */
+int dr_context_get_option(const dr_context* c, const char* name, int* value);
 
 /* One CudaStarter call.  settings13 = { cam.xyz, look.xyz, aperture, focus, fov, max_depth,
  * spp, divisor, backtex } exactly as packed at K:2581; W,H = SCREEN_WIDTH/HEIGHT;

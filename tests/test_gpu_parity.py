@@ -314,10 +314,13 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         assert np.array_equal(acc, base), opts
     for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2}.items():
         ctx.set_option(k, v)
+    assert ctx.get_option("park_min") == 8 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
     with pytest.raises(dr.DogerayError):
         ctx.set_option("park_min", 7)
     with pytest.raises(dr.DogerayError):
         ctx.set_option("no_such_option", 1)
+    with pytest.raises(dr.DogerayError):
+        ctx.get_option("no_such_option")
 
 
 def test_accumulator_tensor_aliases_device_memory(dr, ctx, synth):
