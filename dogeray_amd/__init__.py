@@ -17,7 +17,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libdogeray_amd.so")
+_LIB_PATH = os.environ.get("DOGERAY_AMD_LIB") or os.path.join(_HERE, "libdogeray_amd.so")      # the override serves kernel experiments
 
 TRAVERSAL_THREADED = 0
 TRAVERSAL_ORDERED = 1
