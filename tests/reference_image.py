@@ -1,0 +1,121 @@
+"""Comparison against the reference's OWN saved output (tests/golden/reference_image/, made by
+tests/golden/make_reference_image_fixture.py from images/eorovan.blend.rts.bmp + samples/eorovan.blend.rts).
+
+The reference seeds its RNG from clock() (K:1065) and the number of frames it had accumulated when the image was
+saved is unknown, so the comparison is statistical, per region:
+  * sky: every primary ray that leaves the scene is coloured by the background gradient (K:973-976) -- no randomness
+    beyond the sub-pixel jitter, so these pixels must agree to a grey level;
+  * silhouette: which pixels are sky at all (camera K:1016-1073, BVH, intersection);
+  * the floor left of the van: an untextured glossy plane reflecting the sky (scatter statistics of its material).
+The van itself is textured with eurovan_dif_red.ppm, which the reference tree does not hold: not compared.
+"""
+import gzip
+import os
+
+import numpy as np
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_image")
+W, H = 1280, 720                 # the reference's default window (K:29-30); the scene's '*' line gives no size
+HORIZON = 440                    # rows above this hold no floor
+
+
+def scene_path(tmpdir):
+    """The gzipped scene text, unpacked (the readers take a file name)."""
+    out = os.path.join(str(tmpdir), "eorovan.blend.rts")
+    if not os.path.exists(out):
+        with gzip.open(os.path.join(HERE, "eorovan.blend.rts.gz"), "rb") as f, open(out, "wb") as g:
+            g.write(f.read())
+    return out
+
+
+def reference_image():
+    from PIL import Image
+    return np.asarray(Image.open(os.path.join(HERE, "eorovan.blend.rts.png")).convert("RGB")).astype(np.float64)   # [H, W, 3]
+
+
+def display(acc_whc, frames):
+    """clamp(sum / frames, 0, 255) (K:2287), as an [H, W, 3] image."""
+    return np.clip(acc_whc.astype(np.int64) // frames, 0, 255).astype(np.float64).transpose(1, 0, 2)
+
+
+def sky_mask(img):
+    """Pixels that show the background: equal (within 3 levels) to their row's colour at the left edge, above the floor."""
+    row = np.median(img[:, :20], axis=1, keepdims=True)
+    return (np.abs(img - row).max(axis=2) <= 3) & (np.arange(H)[:, None] < HORIZON)
+
+
+def compare(mine, ref):
+    d = mine - ref
+    a, b = sky_mask(mine), sky_mask(ref)
+    both = a & b
+    floor = d[560:700, 0:200]
+    return {
+        "sky_pixels": int(both.sum()),
+        "sky_mean_abs": float(np.abs(d[both]).mean()),
+        "sky_max_abs": float(np.abs(d[both]).max()),
+        "silhouette_iou": float((a & b).sum() / (a | b).sum()),
+        "floor_mean_abs": float(np.abs(floor).mean()),
+        "floor_mean_signed": [float(v) for v in floor.mean(axis=(0, 1))],
+    }
+
+
+def check(stats):
+    assert stats["sky_pixels"] > 450000                      # half the frame is sky in both
+    assert stats["sky_mean_abs"] < 0.05 and stats["sky_max_abs"] <= 2, stats
+    assert stats["silhouette_iou"] > 0.995, stats
+    assert stats["floor_mean_abs"] < 1.0 and max(abs(v) for v in stats["floor_mean_signed"]) < 0.3, stats
+
+
+# ---- second pair: images/bolter2.blend.rts.bmp <- samples/bolter2.blend.rts (+ boltersmall.ppm, env.ppm)
+# Everything is compared here: the textured gun (albedo lookup K:830), the environment map (K:962), the camera.
+# The saved frame was taken after LEFT x3, DOWN x2 (campos.x - 3, campos.z + 2; K:2354-2376) -- recovered by a search
+# over the key-step lattice, the only free parameters of the reference's window.
+BOLTER_KEYS = (-3.0, 0.0, +2.0)
+
+
+def bolter_scene(tmpdir):
+    """Unpacks the scene and writes the two textures back as binary PPM (P6, maxval 255: the files' own header);
+    returns (scene path, texture directory)."""
+    from PIL import Image
+    d = os.path.join(str(tmpdir), "bolter")
+    os.makedirs(d, exist_ok=True)
+    out = os.path.join(d, "bolter2.blend.rts")
+    if not os.path.exists(out):
+        with gzip.open(os.path.join(HERE, "bolter2.blend.rts.gz"), "rb") as f, open(out, "wb") as g:
+            g.write(f.read())
+        for tex in ("boltersmall", "env"):
+            im = Image.open(os.path.join(HERE, tex + ".png")).convert("RGB")
+            with open(os.path.join(d, tex + ".ppm"), "wb") as g:
+                g.write(b"P6\n%d %d\n255\n" % im.size + im.tobytes())
+    return out, d
+
+
+def bolter_reference_image():
+    from PIL import Image
+    return np.asarray(Image.open(os.path.join(HERE, "bolter2.blend.rts.png")).convert("RGB")).astype(np.float64)
+
+
+def blocks(x, k):
+    h, w = x.shape[0] // k * k, x.shape[1] // k * k
+    return x[:h, :w].reshape(h // k, k, w // k, k, 3).mean(axis=(1, 3))
+
+
+def compare_full(mine, ref):
+    d = mine - ref
+    return {
+        "mean_abs": float(np.abs(d).mean()),
+        "median_abs": float(np.median(np.abs(d))),
+        "mean_signed": [float(v) for v in d.mean(axis=(0, 1))],
+        "within_8_levels": float((np.abs(d).max(axis=2) <= 8).mean()),
+        "block16_mean_abs": float(np.abs(blocks(mine, 16) - blocks(ref, 16)).mean()),
+        "block16_corr": float(np.corrcoef(blocks(mine, 16).ravel(), blocks(ref, 16).ravel())[0, 1]),
+    }
+
+
+def check_full(stats):
+    """What is left is Monte-Carlo noise (the reference's frame count and clock() seed are unknown): small, unbiased, and
+    gone once pixels are averaged over 16x16 blocks."""
+    assert stats["mean_abs"] < 2.0 and stats["median_abs"] <= 1.0, stats
+    assert max(abs(v) for v in stats["mean_signed"]) < 0.3, stats
+    assert stats["within_8_levels"] > 0.95, stats
+    assert stats["block16_mean_abs"] < 0.4 and stats["block16_corr"] > 0.9999, stats

@@ -411,3 +411,41 @@ def test_degenerate_settings(dr, orc, ctx, tmp_path, kernel):
         _assert_frames(g, r, "degenerate %dx%d kernel %d" % (W, H, kernel))
         assert stats["rays"] == rc["rays"]
         assert not g[(W // 8) * 8:].any() and not g[:, (H // 8) * 8:].any()
+
+
+def test_gpu_reproduces_the_reference_image(dr, ctx, tmp_path):
+    """The reference's own saved frame for samples/eorovan.blend.rts (tests/reference_image.py) against 64 frames
+    accumulated on the GPU through the C ABI: sky to a grey level, silhouette, untextured glossy floor."""
+    import reference_image as ri
+    sc = dr.Scene.load(ri.scene_path(tmp_path), "")
+    sc.build_bvh()
+    ctx.upload(sc)
+    s = sc.settings()
+    assert (s.width, s.height) == (ri.W, ri.H)
+    st = dr.pack_settings13(s, 1)
+    frames = 64
+    ctx.accum_reset(ri.W, ri.H)
+    ctx.render_accumulate(st, ri.W, ri.H, s.background, 1, 1000003, frames)
+    stats = ri.compare(ri.display(ctx.accum_read(), frames), ri.reference_image())
+    print(stats)
+    ri.check(stats)
+
+
+def test_gpu_reproduces_the_reference_image_with_textures(dr, ctx, tmp_path):
+    """The reference's saved frame for samples/bolter2.blend.rts (albedo texture, environment map, camera after
+    LEFT x3 DOWN x2) against 64 frames accumulated on the GPU."""
+    import reference_image as ri
+    path, texdir = ri.bolter_scene(tmp_path)
+    sc = dr.Scene.load(path, texdir)
+    sc.build_bvh()
+    ctx.upload(sc)
+    s = sc.settings()
+    assert (s.width, s.height) == (ri.W, ri.H) and s.backtex >= 0
+    s.campos[0] += ri.BOLTER_KEYS[0]; s.campos[1] += ri.BOLTER_KEYS[1]; s.campos[2] += ri.BOLTER_KEYS[2]
+    st = dr.pack_settings13(s, 1)
+    frames = 64
+    ctx.accum_reset(ri.W, ri.H)
+    ctx.render_accumulate(st, ri.W, ri.H, s.background, 1, 1000003, frames)
+    stats = ri.compare_full(ri.display(ctx.accum_read(), frames), ri.bolter_reference_image())
+    print(stats)
+    ri.check_full(stats)

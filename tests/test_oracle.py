@@ -1,8 +1,10 @@
 """CPU tests of the oracle (oracle/dogeray_oracle.cpp) itself.
 
-PARITY UNPINNED: the reference holds no golden vectors for this path (no tests; RNG seeded from
-clock(), K:1065) and cannot be built here, so nothing below compares against reference OUTPUT.
-What is checked: (1) the oracle against its own committed digests (a change to the restatement must
+The reference has no tests and cannot be built here, and its RNG is seeded from clock() (K:1065), so no
+bit-exact reference vector exists.  What pins the oracle is the one OUTPUT the reference tree holds together
+with its input: images/eorovan.blend.rts.bmp, saved by the reference for samples/eorovan.blend.rts
+(test_oracle_reproduces_the_reference_image, statistical: sky to a grey level, silhouette, floor).
+Also checked: (1) the oracle against its own committed digests (a change to the restatement must
 be deliberate), (2) structural facts the reference source implies (node counts K:2073, link
 structure K:1720-1742, children allocated in pairs K:1770/1807, margins K:2633), (3) how far the
 one documented libm liberty (contract C1, pow(x,2) := x*x) can move pixels.
@@ -154,3 +156,41 @@ def test_reader_errors(orc, tmp_path):
     s = orc.Scene(str(one))
     with pytest.raises(RuntimeError):
         s.build_bvh()                                     # N < 2: the reference recurses without bound
+
+
+def test_oracle_reproduces_the_reference_image(orc, tmp_path):
+    """The reference's own saved frame for samples/eorovan.blend.rts (tests/reference_image.py): 16 oracle frames."""
+    import reference_image as ri
+    sc = orc.Scene(ri.scene_path(tmp_path), "")
+    sc.build_bvh()
+    s = sc.settings()
+    assert (s.width, s.height) == (ri.W, ri.H) and s.backtex == -1
+    st = orc.settings13(s, 1)
+    acc = np.zeros((ri.W, ri.H, 3), dtype=np.int64)
+    frames = 16
+    for k in range(frames):
+        img, _ = sc.render(st, ri.W, ri.H, s.background, 1 + 1000003 * k, nthreads=os.cpu_count() or 1)
+        acc += img
+    stats = ri.compare(ri.display(acc, frames), ri.reference_image())
+    print(stats)
+    ri.check(stats)
+
+
+def test_oracle_reproduces_the_reference_image_with_textures(orc, tmp_path):
+    """The reference's saved frame for samples/bolter2.blend.rts: albedo texture, environment map, camera keys."""
+    import reference_image as ri
+    path, texdir = ri.bolter_scene(tmp_path)
+    sc = orc.Scene(path, texdir)
+    sc.build_bvh()
+    s = sc.settings()
+    assert (s.width, s.height) == (ri.W, ri.H) and s.backtex >= 0 and len(sc.textures()) == 2
+    s.campos[0] += ri.BOLTER_KEYS[0]; s.campos[1] += ri.BOLTER_KEYS[1]; s.campos[2] += ri.BOLTER_KEYS[2]
+    st = orc.settings13(s, 1)
+    acc = np.zeros((ri.W, ri.H, 3), dtype=np.int64)
+    frames = 16
+    for k in range(frames):
+        img, _ = sc.render(st, ri.W, ri.H, s.background, 1 + 1000003 * k, nthreads=os.cpu_count() or 1)
+        acc += img
+    stats = ri.compare_full(ri.display(acc, frames), ri.bolter_reference_image())
+    print(stats)
+    ri.check_full(stats)
