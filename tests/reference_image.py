@@ -61,7 +61,7 @@ def compare(mine, ref):
 
 def check(stats):
     assert stats["sky_pixels"] > 450000                      # half the frame is sky in both
-    assert stats["sky_mean_abs"] < 0.05 and stats["sky_max_abs"] <= 2, stats
+    assert stats["sky_mean_abs"] < 0.05 and stats["sky_max_abs"] <= 3, stats      # 3 = the mask's own tolerance (edge pixels)
     assert stats["silhouette_iou"] > 0.995, stats
     assert stats["floor_mean_abs"] < 1.0 and max(abs(v) for v in stats["floor_mean_signed"]) < 0.3, stats
 
