@@ -46,21 +46,28 @@ bool write_ppm(const std::string& path, const std::vector<uint8_t>& rgb, int W, 
   return ok;
 }
 
-// 24-bit bottom-up BMP (the reference saves the window surface with SDL_SaveBMP, K:2505-2513)
+// The file the reference's export key writes (SDL_SaveBMP of an ARGB8888 surface, K:2505-2513), byte for byte in
+// layout: BITMAPV4HEADER (108 bytes), 32 bits per pixel, BI_BITFIELDS with masks R 00ff0000 G 0000ff00 B 000000ff
+// A ff000000, colour space 'Win ', rows bottom-up, alpha 255 -- checked against images/eorovan.blend.rts.bmp.
 bool write_bmp(const std::string& path, const std::vector<uint8_t>& rgb, int W, int H) {
   FILE* f = fopen(path.c_str(), "wb");
   if (!f) return false;
-  const uint32_t row = ((uint32_t)W * 3 + 3) & ~3u, size = row * (uint32_t)H;
-  uint8_t hdr[54] = {'B', 'M'};
+  const uint32_t row = (uint32_t)W * 4, size = row * (uint32_t)H;
+  uint8_t hdr[122] = {'B', 'M'};
   auto put32 = [&](int off, uint32_t v) { memcpy(hdr + off, &v, 4); };
   auto put16 = [&](int off, uint16_t v) { memcpy(hdr + off, &v, 2); };
-  put32(2, 54 + size); put32(10, 54); put32(14, 40); put32(18, (uint32_t)W); put32(22, (uint32_t)H);
-  put16(26, 1); put16(28, 24); put32(34, size); put32(38, 2835); put32(42, 2835);
+  put32(2, 122 + size); put32(10, 122); put32(14, 108); put32(18, (uint32_t)W); put32(22, (uint32_t)H);
+  put16(26, 1); put16(28, 32); put32(30, 3); put32(34, size);
+  put32(54, 0x00ff0000u); put32(58, 0x0000ff00u); put32(62, 0x000000ffu); put32(66, 0xff000000u);
+  put32(70, 0x57696e20u);                                    // LCS_WINDOWS_COLOR_SPACE, "Win "
   bool ok = fwrite(hdr, 1, sizeof(hdr), f) == sizeof(hdr);
   std::vector<uint8_t> line(row, 0);
   for (int y = H - 1; y >= 0 && ok; y--) {
     const uint8_t* src = &rgb[(size_t)y * W * 3];
-    for (int x = 0; x < W; x++) { line[(size_t)x * 3] = src[(size_t)x * 3 + 2]; line[(size_t)x * 3 + 1] = src[(size_t)x * 3 + 1]; line[(size_t)x * 3 + 2] = src[(size_t)x * 3]; }
+    for (int x = 0; x < W; x++) {
+      line[(size_t)x * 4] = src[(size_t)x * 3 + 2]; line[(size_t)x * 4 + 1] = src[(size_t)x * 3 + 1];
+      line[(size_t)x * 4 + 2] = src[(size_t)x * 3]; line[(size_t)x * 4 + 3] = 255;
+    }
     ok = fwrite(line.data(), 1, row, f) == row;
   }
   fclose(f);

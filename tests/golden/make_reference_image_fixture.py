@@ -26,4 +26,7 @@ with open(os.path.join(REF, "samples", "bolter2.blend.rts"), "rb") as f, gzip.Gz
     shutil.copyfileobj(f, g)
 for tex in ("boltersmall", "env"):      # P6 pixel data, re-encoded losslessly (the test writes them back as P6)
     Image.open(os.path.join(REF, "samples", tex + ".ppm")).convert("RGB").save(os.path.join(OUT, tex + ".png"), optimize=True)
+# the 122 header bytes of the saved BMP: the export format dogeray_main.cpp reproduces
+with open(os.path.join(REF, "images", "eorovan.blend.rts.bmp"), "rb") as f, open(os.path.join(OUT, "eorovan.blend.rts.bmp.header"), "wb") as g:
+    g.write(f.read(122))
 print({n: os.path.getsize(os.path.join(OUT, n)) for n in sorted(os.listdir(OUT))})

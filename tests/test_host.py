@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, SCENES, SCENEGEN
+from conftest import GOLDEN, ROOT, SCENES, SCENEGEN
 
 
 @pytest.fixture(scope="module")
@@ -242,7 +242,10 @@ def test_host_application_reports_missing_gpu_or_renders(tmp_path):
     if torch.cuda.is_available():
         assert r.returncode == 0, r.stderr
         data = open(out, "rb").read()
-        assert data[:2] == b"BM" and len(data) == 54 + 128 * 128 * 3
+        assert data[:2] == b"BM" and len(data) == 122 + 128 * 128 * 4          # the layout SDL_SaveBMP gives the reference's export
+        ref_hdr = open(os.path.join(GOLDEN, "reference_image", "eorovan.blend.rts.bmp.header"), "rb").read()
+        same = [i for i in range(122) if i not in range(2, 6) and i not in range(18, 26) and i not in range(34, 38)]    # all but the three size fields
+        assert all(data[i] == ref_hdr[i] for i in same)
     else:
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
 
