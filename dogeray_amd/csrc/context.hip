@@ -354,7 +354,8 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __rest
     atomicAdd(&total_cost, sum);
   }
   __syncthreads();
-  const unsigned long long threshold = heavy_factor > 0 ? (total_cost * (unsigned long long)heavy_factor) / (unsigned long long)(ntiles > 0 ? ntiles : 1) : ~0ull;
+  const unsigned long long threshold = heavy_factor > 0 ? (total_cost * (unsigned long long)heavy_factor) / (unsigned long long)(ntiles > 0 ? ntiles : 1)
+                                                       : (heavy_factor < 0 ? 0ull : ~0ull);       // -1: every tile by cost, 0: all natural
   auto region_of = [&](int t) { return (int)(((long long)t * regions) / ntiles); };
   auto heavy = [&](int t) { return (unsigned long long)tile_cost[t] > threshold; };
   auto key_of = [&](int t) {
@@ -502,7 +503,7 @@ struct dr_context {
   int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
-  int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural)
+  int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural, -1 = all by cost)
   int coop_steps = 64;      // persistent kernel, drain phase: rays older than this are finished cooperatively (0 = off)
   int coop_lanes = 8;       // ... in waves with at most this many lanes still walking
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
@@ -708,7 +709,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "occupancy") { if (v != 4 && v != 5 && v != 6) goto bad; c->occupancy = v; }
   else if (name == "trav_min") { if (v != 32 && v != 48) goto bad; c->trav_min = v; }
   else if (name == "park_min") { if (v != 0 && v != 8 && v != 16) goto bad; c->park_min = v; }
-  else if (name == "heavy_factor") { if (v < 0 || v > 1000) goto bad; c->heavy_factor = v; c->order_valid = false; }
+  else if (name == "heavy_factor") { if (v < -1 || v > 1000) goto bad; c->heavy_factor = v; c->order_valid = false; }
   else if (name == "coop_steps") { if (v < 0) goto bad; c->coop_steps = v; }
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }

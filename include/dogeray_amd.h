@@ -154,7 +154,8 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *   "trav_min"      32 or 48;  "park_min"  0, 8 or 16;  "unroll"  1, 2 (default) or 3   (persistent kernel scheduling)
  *   "xcd_regions"   1 (default): one tile queue per XCD, each an image band, with stealing; 0: one queue
  *   "heavy_factor"  with feedback: tiles that cost more than this many times the mean start first (most expensive
- *                   first), all others keep their natural order (default 1: the above-average tiles)
+ *                   first), all others keep their natural order (default 1: the above-average tiles; 0: no tile is
+ *                   reordered, -1: every tile by cost)
  *   "coop_steps"    once the tile queue is empty, a ray older than this many node steps is finished by all 64
  *                   lanes of its wave together (default 64, 0 = off), in waves with at most "coop_lanes" (8) lanes walking
  * The environment variable DOGERAY_OPTIONS="name=value,..." applies the same at context creation. */

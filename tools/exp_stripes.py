@@ -10,8 +10,12 @@ sc = dr.Scene.load(path, ""); sc.build_bvh(); s = sc.settings()
 ctx = dr.Context(0).upload(sc)
 st = dr.pack_settings13(s, 1, spp=1)
 W, H = s.width, s.height
+import os
+for kv in os.environ.get("EXP_OPTIONS", "").split(","):
+    if kv: ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+worlds = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else [1, 2, 4, 8]
 base = None
-for world in (1, 2, 4, 8):
+for world in worlds:
     worst, total = 0.0, 0.0
     per = []
     for rank in range(world):
