@@ -253,11 +253,14 @@ __device__ __forceinline__ void trav_step_park(WalkRsrc walk, V3 o, V3 inv, Trav
   if (leaf) { pk.C = ld_unit_raw(walk, off + 32); pk.D = ld_unit_raw(walk, off + 48); }
   float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
   const int w0 = __float_as_int(A.w);
-  const int next_miss = leaf ? leaf_successor<COUNT>(tr.node, w0) : __float_as_int(B.w);
+  // selects, not branches: both sides are two or three instructions, a divergent branch costs more than that
+  const int succ = leaf_successor<COUNT>(tr.node, w0);
+  const int next_miss = leaf ? succ : __float_as_int(B.w);
   float dist;
   if (COUNT) c.V++;
   bool h = slab(o, inv, mn, mx, dist) && dist < tr.best_t;
-  if (leaf) { pk.info = w0; pk.v0x = B.w; }
+  pk.info = leaf ? w0 : pk.info;
+  pk.v0x = leaf ? B.w : pk.v0x;
   pk.parked = h && leaf;
   tr.node = (h && !leaf) ? w0 : next_miss;
 }
