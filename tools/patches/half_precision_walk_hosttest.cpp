@@ -19,7 +19,7 @@ int main(int argc, char** argv) {
   const HostScene& S = sc.host;
   printf("walk units %zu, hwalk units %zu\n", img.walk.size(), img.hwalk.size());
   if (img.hwalk.empty()) return 0;
-  const unsigned END = (unsigned)img.hwalk.size() << 1;
+  
   std::mt19937 rng(5); std::uniform_real_distribution<float> U(-1, 1);
   int nrays = argc > 2 ? atoi(argv[2]) : 2000; long se = 0, sh = 0;
   for (int r = 0; r < nrays; r++) {
@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
     std::vector<int> la, lb;
     { int node = 0; while (node >= 0) { const dr_bvh_node& b = S.bvh[node]; float dist; bool h = slab(o, inv, b.min, b.max, dist); se++; if (b.end) { if (h) la.push_back(b.under); node = b.miss_node; } else node = h ? b.hit_node : b.miss_node; } }
     { int node = 0; long guard = 0;
-      while ((unsigned)node < END) {
+      while (node >= 0) {
         if (++guard > 100000000) { printf("hwalk does not end\n"); return 1; }
         bool leaf = node & 1; size_t u = (size_t)(node >> 1); sh++;
         if (u + (leaf ? 4 : 1) > img.hwalk.size()) { printf("OOB link %d\n", node); return 1; }
@@ -42,7 +42,7 @@ int main(int argc, char** argv) {
           unsigned w[4]; memcpy(w, img.hwalk[u].f, 16);
           float mn[3] = {h2f(w[0] & 0xffff), h2f(w[0] >> 16), h2f(w[1] & 0xffff)}, mx[3] = {h2f(w[1] >> 16), h2f(w[2] & 0xffff), h2f(w[2] >> 16)};
           float dist; bool h = slab(o, inv, mn, mx, dist);
-          node = h ? node + 2 + (int)((w[3] >> 30) & 1u) : (int)(w[3] & ~(1u << 30));
+          node = h ? node + 2 + (int)(w[3] >> 31) : (int)(w[3] & 0x7fffffffu) - 1;
         }
       } }
     if (la != lb) { printf("ray %d: leaf sequences differ (%zu vs %zu)\n", r, la.size(), lb.size()); return 1; }
