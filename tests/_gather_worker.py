@@ -36,6 +36,18 @@ def main():
             ok = ok and np.array_equal(full, want)
         else:
             assert full is None
+    # the bench's form: one FrameGatherer, its buffers reused for every gather (two different frames through the same buffers)
+    import torch
+    g = None
+    for seed in (21, 22):
+        mine, _ = s.render(s13, W, H, st.background, seed, nthreads=2, col_mod=world, col_rem=rank)
+        acc = torch.from_numpy(np.ascontiguousarray(mine).reshape(-1))
+        if g is None:
+            g = multigpu.FrameGatherer(acc, W, H, world, rank)
+        full = g.gather(acc)
+        if rank == 0:
+            want, _ = s.render(s13, W, H, st.background, seed, nthreads=2)
+            ok = ok and np.array_equal(full.numpy().reshape(W, H, 3), want)
     if rank == 0:
         with open(out_path, "w") as f:
             f.write("OK" if ok else "MISMATCH")
