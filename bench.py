@@ -131,7 +131,7 @@ def main():
     ap.add_argument("--verts", type=int, default=709, help="heightfield vertices per side (709 -> 1 002 528 triangles)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--traversal", choices=["threaded", "ordered"], default="threaded")
+    ap.add_argument("--traversal", choices=["wide", "threaded", "ordered"], default="wide")
     ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch (default 32 x GPUs, at most 256: a launch has to outlast its longest pixel, ~3 ms)")
     ap.add_argument("--gather-every", type=int, default=0, help="frames between two gathers to rank 0 (default: --batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -194,7 +194,7 @@ def main():
     t0 = time.time()
     ctx.upload(scene)
     t_upload = time.time() - t0
-    mode = dr.TRAVERSAL_ORDERED if args.traversal == "ordered" else dr.TRAVERSAL_THREADED
+    mode = {"wide": dr.TRAVERSAL_WIDE, "ordered": dr.TRAVERSAL_ORDERED, "threaded": dr.TRAVERSAL_THREADED}[args.traversal]
     ctx.set_traversal(mode)
     ctx.set_stripe(world, rank)
     if args.gather_every <= 0:

@@ -21,6 +21,7 @@ _LIB_PATH = os.environ.get("DOGERAY_AMD_LIB") or os.path.join(_HERE, "libdogeray
 
 TRAVERSAL_THREADED = 0
 TRAVERSAL_ORDERED = 1
+TRAVERSAL_WIDE = 2          # the default: 4-way tree over the reference's leaves
 KERNEL_TILE = 0
 KERNEL_PERSISTENT = 1
 ERR_INVALID, ERR_IO, ERR_PARSE, ERR_SCENE, ERR_DEVICE, ERR_NOMEM = -1, -2, -3, -4, -5, -6      # enum dr_status

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdogeray_amd.so")
-HOST_SOURCES = ["rts_reader.cpp", "bvh_builder.cpp", "linearise.cpp", "capi_host.cpp"]
+HOST_SOURCES = ["rts_reader.cpp", "bvh_builder.cpp", "linearise.cpp", "wide_builder.cpp", "capi_host.cpp"]
 DEVICE_SOURCES = ["context.hip"]
 # -ffp-contract=off: no FMA contraction on host or device -- the BVH build and the kernel's
 # arithmetic are specified operation by operation (DESIGN.md "arithmetic contract").

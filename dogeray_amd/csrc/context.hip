@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstring>
+#include <exception>
 #include <string>
 #include <vector>
 
@@ -21,7 +22,7 @@ namespace dr {
 // column-major framebuffer gives each wave eight 96-byte runs).
 template <bool COUNT, int MODE, int OCC>
 __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
-  __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : 1];
+  __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : (MODE == DR_TRAVERSAL_WIDE ? WIDE_STACK * 256 : 1)];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int tile = blockIdx.x * 4 + wave;
   Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -32,6 +33,11 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
     if (MODE == DR_TRAVERSAL_ORDERED) {
       int* stack = lds_stack + wave * (ORDERED_STACK * 64) + lane;
       auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_ordered<COUNT>(P.pairs, P.prims, o, d, cc, stack); };
+      render_pixel<COUNT>(P, closest, x, y, c);
+    } else if (MODE == DR_TRAVERSAL_WIDE) {
+      const WalkRsrc wide = wide_rsrc(P);
+      int* stack = lds_stack + wave * (WIDE_STACK * 64) + lane;
+      auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_wide<COUNT>(wide, o, d, cc, stack); };
       render_pixel<COUNT>(P, closest, x, y, c);
     } else {
       const WalkRsrc walk = walk_rsrc(P);
@@ -64,7 +70,11 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 //
 // lane states (kept in `tr.node`): >= 0 walking; -1 walk finished, needs shading; -2 needs a new
 // sample or pixel; -3 retired.
-template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL>
+// WIDE: the lanes walk the 4-way tree (wide_node_step / wide_leaf_step) instead of the threaded links.  A lane whose
+// next record is a leaf waits until PARK_MIN lanes have one (the leaf step -- exact box + triangle -- is the long
+// block, as the parked triangle test is in the threaded walk); its stack lives in the first WIDE_STACK words of
+// the wave's LDS region, the phase stash behind it.
+template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE>
 __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, const int* __restrict__ region_start,
                                                                      unsigned* __restrict__ pixel_cost) {
@@ -75,11 +85,14 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   //    and while a hit is shaded also the pixel bookkeeping) waits here -- the shading code is where
   //    register pressure peaks, and this keeps the kernel at 96 VGPRs = 5 waves per SIMD;
   //  * outside the phase, the node stack of the cooperative drain (COOP_STACK entries).
-  __shared__ int wave_lds[4 * WAVE_LDS_DWORDS];
-  int* const my_lds = wave_lds + (threadIdx.x >> 6) * WAVE_LDS_DWORDS;
+  constexpr int REGION = WIDE ? (WIDE_STACK + WIDE_STASH) * 64 : WAVE_LDS_DWORDS;
+  __shared__ int wave_lds[4 * REGION];
+  int* const my_lds = wave_lds + (threadIdx.x >> 6) * REGION;
+  int* const my_stack = my_lds + lane;                             // WIDE: word k of this lane's stack at my_stack[k * 64]
+  WideStack ws; ws.top = 0u; ws.sp = 0;
   const int ntiles = P.ncols * P.gy;
   const int nwork = ntiles * P.batch;          // queue length: every tile of every frame of the batch
-  const WalkRsrc walk = walk_rsrc(P);
+  const WalkRsrc walk = WIDE ? wide_rsrc(P) : walk_rsrc(P);
   Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
   // wave-uniform work cursor
   // The queue hands out positions q = 0, 1, 2, ...; tile_order (when present) maps a position to
@@ -122,8 +135,16 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
       const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked);
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
-      float* const st = reinterpret_cast<float*>(my_lds) + lane;      // slot k of this lane: st[k * 64]
-      {
+      float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? WIDE_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
+      if (WIDE) {
+        st[0 * 64] = __uint_as_float(ws.top); st[1 * 64] = __int_as_float(ws.sp);
+        st[11 * 64] = inv.x; st[12 * 64] = inv.y; st[13 * 64] = inv.z;
+        st[2 * 64] = color.x; st[3 * 64] = color.y; st[4 * 64] = color.z;
+        st[5 * 64] = __int_as_float(px); st[6 * 64] = __int_as_float(py); st[7 * 64] = __int_as_float(pcode);
+        st[8 * 64] = __int_as_float(frame); st[9 * 64] = __int_as_float(sample);
+        st[10 * 64] = __uint_as_float(steps); st[14 * 64] = __uint_as_float(rstart);
+        asm volatile("" ::: "memory");
+      } else {
         st[0 * 64] = pk.v0x; st[1 * 64] = __uint_as_float(pk.C.x); st[2 * 64] = __uint_as_float(pk.C.y); st[3 * 64] = __uint_as_float(pk.C.z); st[4 * 64] = __uint_as_float(pk.C.w);
         st[5 * 64] = __uint_as_float(pk.D.x); st[6 * 64] = __uint_as_float(pk.D.y); st[7 * 64] = __uint_as_float(pk.D.z); st[8 * 64] = __uint_as_float(pk.D.w);
         st[9 * 64] = __int_as_float(pk.info); st[10 * 64] = pk.parked ? 1.0f : 0.0f;
@@ -150,7 +171,13 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           ended = true;
         }
       }
-      {
+      if (WIDE) {
+        asm volatile("" ::: "memory");
+        color = mk(st[2 * 64], st[3 * 64], st[4 * 64]);
+        px = __float_as_int(st[5 * 64]); py = __float_as_int(st[6 * 64]); pcode = __float_as_int(st[7 * 64]);
+        frame = __float_as_int(st[8 * 64]); sample = __float_as_int(st[9 * 64]);
+        steps = __float_as_uint(st[10 * 64]); rstart = __float_as_uint(st[14 * 64]);
+      } else {
         asm volatile("" ::: "memory");
         color = mk(st[14 * 64], st[15 * 64], st[16 * 64]);
         px = __float_as_int(st[17 * 64]); py = __float_as_int(st[18 * 64]); pcode = __float_as_int(st[19 * 64]);
@@ -242,7 +269,12 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           fresh_ray = true;
         }
       }
-      {
+      if (WIDE) {
+        asm volatile("" ::: "memory");
+        ws.top = __float_as_uint(st[0 * 64]); ws.sp = __float_as_int(st[1 * 64]);
+        inv = mk(st[11 * 64], st[12 * 64], st[13 * 64]);
+        if (fresh_ray) { inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z); ws.top = 0u; ws.sp = 0; }
+      } else {
         asm volatile("" ::: "memory");
         pk.v0x = st[0 * 64]; pk.C = u32x4{__float_as_uint(st[1 * 64]), __float_as_uint(st[2 * 64]), __float_as_uint(st[3 * 64]), __float_as_uint(st[4 * 64])};
         pk.D = u32x4{__float_as_uint(st[5 * 64]), __float_as_uint(st[6 * 64]), __float_as_uint(st[7 * 64]), __float_as_uint(st[8 * 64])};
@@ -253,7 +285,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
       if (__ballot(tr.node != -3) == 0ull) break;
     }
-    if (!COUNT && P.coop_steps > 0 && cur_tile >= ntiles && (int)__popcll(walking) <= P.coop_lanes) {
+    if (!WIDE && !COUNT && P.coop_steps > 0 && cur_tile >= ntiles && (int)__popcll(walking) <= P.coop_lanes) {
       // ---- draining (the queue is empty) and only a few lanes of this wave still walk: a ray that is
       // already old is finished by the whole wave at once (coop_closest_hit) instead of holding the launch
       // open for hundreds of further dependent steps.  (The counting build keeps the plain walk so that
@@ -275,7 +307,26 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         }
       }
     }
-    if (PARK_MIN > 0) {
+    if (WIDE) {
+      // ---- leaf records (exact box + primitive) once enough lanes stand at one, or nobody can take a node step
+      const bool at_leaf = tr.node >= 0 && (tr.node & 1);
+      const unsigned long long leaves = __ballot(at_leaf);
+      const unsigned long long nodes = __ballot(tr.node >= 0 && !(tr.node & 1));
+      if (leaves != 0ull && ((int)__popcll(leaves) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes == 0ull || cur_tile >= ntiles)) {
+        if (at_leaf) {
+          if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
+          wide_leaf_step<COUNT>(walk, path.rayo, path.raydir, inv, tr, ws, my_stack, c);
+          steps++;
+        }
+      }
+      for (int u = 0; u < P_UNROLL; u++) {
+        if (tr.node >= 0 && !(tr.node & 1)) {
+          if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
+          wide_node_step<COUNT>(walk, path.rayo, inv, tr, ws, my_stack, c);
+          steps++;
+        }
+      }
+    } else if (PARK_MIN > 0) {
       // ---- test the parked leaves once enough lanes hold one (or nobody could step anyway)
       const unsigned long long parked = __ballot(pk.parked);
       const unsigned long long steppers = __ballot(tr.node >= 0 && !pk.parked);
@@ -448,7 +499,7 @@ __global__ void kat_optics_kernel(int n, const float* v, const float* nrm, const
 }
 template <int MODE>
 __global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, const float* o, const float* d, float* t, int32_t* slot, int32_t* visits) {
-  __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : 1];
+  __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : (MODE == DR_TRAVERSAL_WIDE ? WIDE_STACK * 256 : 1)];
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -456,6 +507,9 @@ __global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, con
   if (MODE == DR_TRAVERSAL_ORDERED) {
     int* stack = lds_stack + (threadIdx.x >> 6) * (ORDERED_STACK * 64) + (threadIdx.x & 63);
     h = closest_hit_ordered<true>(P.pairs, P.prims, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
+  } else if (MODE == DR_TRAVERSAL_WIDE) {
+    int* stack = lds_stack + (threadIdx.x >> 6) * (WIDE_STACK * 64) + (threadIdx.x & 63);
+    h = closest_hit_wide<true>(wide_rsrc(P), ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
   } else {
     h = closest_hit_threaded<true>(walk_rsrc(P), ld3(o + 3 * i), ld3(d + 3 * i), c);
   }
@@ -474,6 +528,8 @@ struct dr_context {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // resident scene
   DevUnit* walk = nullptr; size_t walk_bytes = 0;
+  DevUnit* wide = nullptr; size_t wide_bytes = 0; int wide_depth = 0, wide_nodes = 0;   // null: scene not representable (threaded walk is used)
+  int wide_tree = 1;        // structure of the wide walk's tree: 1 binned SAH (default), 0 the reference's topology collapsed
   DevPair* pairs = nullptr;
   DevPrim* prims = nullptr;
   DevShade* shade = nullptr;
@@ -494,7 +550,7 @@ struct dr_context {
   float order_key[16] = {0};       // settings13 + W, H, stripe of the frame the order belongs to
   bool feedback = true;
   int stripe_mod = 1, stripe_rem = 0;
-  int traversal = DR_TRAVERSAL_THREADED;
+  int traversal = DR_TRAVERSAL_WIDE;
   bool count = false;
   // tunables (dr_context_set_option / DOGERAY_OPTIONS)
   int kernel = DR_KERNEL_PERSISTENT;
@@ -568,6 +624,7 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   memset(&P, 0, sizeof(P));
   memcpy(c->cur_settings, st, sizeof(c->cur_settings));
   P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims; P.shade = c->shade; P.tex = c->tex; P.texels = c->texels;
+  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes;
   P.counters = c->counters;
   float aspect = float(W / st[11]) / float(H / st[11]);           // K:1016 (int / float)
   float fov = (float)((double)st[8] * M_PI / 180);                // K:1020
@@ -612,18 +669,22 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
 
 constexpr int TILE_COUNTERS = 1024;
 
-inline bool uses_persistent(const dr_context* c) { return c->kernel == DR_KERNEL_PERSISTENT && c->traversal == DR_TRAVERSAL_THREADED; }
+// the traversal a launch really uses: the wide walk needs its structure (scenes it cannot represent walk the threaded links)
+inline int traversal_of(const dr_context* c) { return (c->traversal == DR_TRAVERSAL_WIDE && !c->wide) ? DR_TRAVERSAL_THREADED : c->traversal; }
+inline bool uses_persistent(const dr_context* c) { return c->kernel == DR_KERNEL_PERSISTENT && traversal_of(c) != DR_TRAVERSAL_ORDERED; }
 
 template <int OCC>
 void launch_tile(dr_context* c, const RenderParams& P) {
   const int tiles = P.ncols * P.gy;
   dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
-  const bool ordered = c->traversal == DR_TRAVERSAL_ORDERED;
+  const int mode = traversal_of(c);
   if (c->count) {
-    if (ordered) hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_ORDERED, OCC>), grid, block, 0, c->stream, P);
+    if (mode == DR_TRAVERSAL_ORDERED) hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_ORDERED, OCC>), grid, block, 0, c->stream, P);
+    else if (mode == DR_TRAVERSAL_WIDE) hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_WIDE, OCC>), grid, block, 0, c->stream, P);
     else hipLaunchKernelGGL((render_kernel<true, DR_TRAVERSAL_THREADED, OCC>), grid, block, 0, c->stream, P);
   } else {
-    if (ordered) hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_ORDERED, OCC>), grid, block, 0, c->stream, P);
+    if (mode == DR_TRAVERSAL_ORDERED) hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_ORDERED, OCC>), grid, block, 0, c->stream, P);
+    else if (mode == DR_TRAVERSAL_WIDE) hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_WIDE, OCC>), grid, block, 0, c->stream, P);
     else hipLaunchKernelGGL((render_kernel<false, DR_TRAVERSAL_THREADED, OCC>), grid, block, 0, c->stream, P);
   }
 }
@@ -635,8 +696,13 @@ void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, 
   int blocks = c->num_cus * OCC;                   // OCC waves per SIMD on every CU
   if (blocks * 4 > work) blocks = (work + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
-  if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
-  else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
+  if (traversal_of(c) == DR_TRAVERSAL_WIDE) {
+    if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
+    else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
+    return;
+  }
+  if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, false>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
+  else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, false>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
 }
 
 // The instantiated tunings; dr_context_set_option only accepts these values.
@@ -716,6 +782,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
+  else if (name == "wide_tree") { if (v != 0 && v != 1) goto bad; c->wide_tree = v; }      // takes effect at the next dr_context_upload_scene
   else { set_error("unknown option '" + name + "'"); return DR_ERR_INVALID; }
   return DR_OK;
 bad:
@@ -790,17 +857,20 @@ int dr_context_create(int device_ordinal, dr_context** out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
   }
-  if (hipMalloc((void**)&c->tile_counters, TILE_COUNTERS * sizeof(unsigned)) != hipSuccess ||
-      hipMemset(c->tile_counters, 0, TILE_COUNTERS * sizeof(unsigned)) != hipSuccess) {
-    set_error("cannot allocate tile counters");
+  memset(&c->stats, 0, sizeof(c->stats));
+  // the stream first: every memset below is ordered on it, like the kernels that use the buffers
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
+      hipEventCreate(&c->ev1) != hipSuccess) {
+    set_error("cannot create stream/events");
     dr_context_destroy(c);
     return DR_ERR_DEVICE;
   }
-  memset(&c->stats, 0, sizeof(c->stats));
-  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-      hipEventCreate(&c->ev1) != hipSuccess || hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
-      hipMemset(c->counters, 0, 16 * sizeof(unsigned long long)) != hipSuccess) {
-    set_error("cannot create stream/events");
+  if (hipMalloc((void**)&c->tile_counters, TILE_COUNTERS * sizeof(unsigned)) != hipSuccess ||
+      hipMemsetAsync(c->tile_counters, 0, TILE_COUNTERS * sizeof(unsigned), c->stream) != hipSuccess ||
+      hipMalloc((void**)&c->counters, 16 * sizeof(unsigned long long)) != hipSuccess ||
+      hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned long long), c->stream) != hipSuccess ||
+      hipStreamSynchronize(c->stream) != hipSuccess) {
+    set_error("cannot allocate tile counters / statistics");
     dr_context_destroy(c);
     return DR_ERR_DEVICE;
   }
@@ -812,7 +882,7 @@ void dr_context_destroy(dr_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* bufs[] = {c->walk, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
+  void* bufs[] = {c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -824,10 +894,22 @@ int dr_context_upload_scene(dr_context* c, const dr_scene* s) {
   if (!c || !s) { set_error("null argument"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
   DeviceImage img;
-  int rc = linearise(s->host, img);
+  int rc = DR_OK;
+  try {
+    rc = linearise(s->host, img, c->wide_tree);
+  } catch (const std::exception& e) {
+    set_error(std::string("scene could not be linearised: ") + e.what());
+    return DR_ERR_NOMEM;
+  }
   if (rc != DR_OK) return rc;
   if ((rc = upload(c->walk, img.walk)) != DR_OK) return rc;
   c->walk_bytes = img.walk.size() * sizeof(DevUnit);
+  if (c->wide) { (void)hipFree(c->wide); c->wide = nullptr; }
+  c->wide_bytes = 0; c->wide_depth = img.wide_depth; c->wide_nodes = img.wide_nodes;
+  if (!img.wide.empty()) {
+    if ((rc = upload(c->wide, img.wide)) != DR_OK) return rc;
+    c->wide_bytes = img.wide.size() * sizeof(DevUnit);
+  }
   if ((rc = upload(c->pairs, img.pairs)) != DR_OK) return rc;
   if ((rc = upload(c->prims, img.prims)) != DR_OK) return rc;
   if ((rc = upload(c->shade, img.shade)) != DR_OK) return rc;
@@ -868,12 +950,16 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_steps") *value = c->coop_steps;
   else if (n == "coop_lanes") *value = c->coop_lanes;
   else if (n == "tree_depth") *value = c->tree_depth;
+  else if (n == "wide_tree") *value = c->wide_tree;
+  else if (n == "wide_depth") *value = c->wide ? c->wide_depth : 0;          // 0: the scene has no wide structure
+  else if (n == "wide_nodes") *value = c->wide ? c->wide_nodes : 0;
+  else if (n == "traversal") *value = traversal_of(c);                        // the traversal launches really use
   else { set_error("unknown option " + n); return DR_ERR_INVALID; }
   return DR_OK;
 }
 
 int dr_context_set_traversal(dr_context* c, int mode) {
-  if (!c || (mode != DR_TRAVERSAL_THREADED && mode != DR_TRAVERSAL_ORDERED)) { set_error("unknown traversal mode"); return DR_ERR_INVALID; }
+  if (!c || (mode != DR_TRAVERSAL_THREADED && mode != DR_TRAVERSAL_ORDERED && mode != DR_TRAVERSAL_WIDE)) { set_error("unknown traversal mode"); return DR_ERR_INVALID; }
   if (mode == DR_TRAVERSAL_ORDERED && c->walk && c->tree_depth > ORDERED_STACK) {
     set_error("ordered traversal supports at most 2^24 primitives");
     return DR_ERR_SCENE;
@@ -996,8 +1082,8 @@ int dr_stats_enable_counters(dr_context* c, int on) {
 int dr_stats_reset(dr_context* c) {
   if (!c) { set_error("null context"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipMemsetAsync(c->counters, 0, 16 * sizeof(unsigned long long), c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  HIP_TRY(hipMemset(c->counters, 0, 16 * sizeof(unsigned long long)));
   memset(&c->stats, 0, sizeof(c->stats));
   return DR_OK;
 }
@@ -1089,8 +1175,10 @@ int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, i
   RenderParams P;
   memset(&P, 0, sizeof(P));
   P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims;
+  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes;
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
-  if (c->traversal == DR_TRAVERSAL_ORDERED) hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p, bv.p);
+  if (traversal_of(c) == DR_TRAVERSAL_WIDE) hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_WIDE>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p, bv.p);
+  else if (c->traversal == DR_TRAVERSAL_ORDERED) hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p, bv.p);
   else hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_THREADED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p, bv.p);
   HIP_TRY(hipStreamSynchronize(c->stream));
   KAT_DO(bt.get(t, (size_t)n));

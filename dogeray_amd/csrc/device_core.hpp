@@ -203,6 +203,9 @@ typedef __amdgpu_buffer_rsrc_t WalkRsrc;
 __device__ __forceinline__ WalkRsrc walk_rsrc(const RenderParams& P) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)P.walk, 0, (int)P.walk_bytes, 0x00020000);
 }
+__device__ __forceinline__ WalkRsrc wide_rsrc(const RenderParams& P) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)P.wide, 0, (int)P.wide_bytes, 0x00020000);
+}
 __device__ __forceinline__ float4 ld_unit(WalkRsrc r, unsigned byte_off) {
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
@@ -282,6 +285,7 @@ __device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk
 // (equal t goes to the lower slot = the leaf the reference's walk reaches first).  Used only while a
 // launch drains (persistent kernel): idle lanes shorten the few long rays that set the launch time.
 constexpr int WAVE_LDS_DWORDS = 24 * 64;  // per-wave LDS region of the persistent kernel (6 KiB): phase stash / cooperative stack
+constexpr int WIDE_STASH = 16;             // phase stash of the WIDE persistent kernel, dwords per lane (behind the WIDE_STACK stack words)
 constexpr int COOP_STACK = WAVE_LDS_DWORDS;   // node stack entries; a deeper frontier falls back to the plain walk
 
 __device__ __forceinline__ float wave_min_f32(float v) {
@@ -356,6 +360,115 @@ __device__ __forceinline__ bool coop_closest_hit(const DevPair* __restrict__ pai
   out.t = best_t;
   out.slot = best_slot == 0x7fffffff ? -1 : best_slot;
   return true;
+}
+
+// ------------------------------------------------------------------ wide walk
+// hit() K:468-512 over the 4-way tree of wide_builder.cpp (device_layout.h "wide walk").  The answer is the
+// lexicographic minimum (t, slot) over the leaves whose own (exact, reference) box the ray enters no farther than
+// the best t -- the reference's hit, by the argument at closest_hit_ordered below: internal boxes only have to
+// ENCLOSE the leaves under them (the host checks every decoded plane with this very fmaf), and the slab test is
+// monotone in the box, so a subtree is skipped only if every leaf in it would fail its own test.
+//
+// Per lane: `node` = record index << 1 | is-leaf; the children of a node that were entered but not yet visited
+// are one word (first child's index << 8 | leaf mask << 4 | pending mask); the newest such word lives in a
+// register (`top`), older ones on a per-lane stack in LDS (word k of lane l at stack[k * 64 + l]: conflict-free).
+struct WideStack { unsigned top; int sp; };
+
+__device__ __forceinline__ float ubyte_f(unsigned w, int k) { return (float)((w >> (8 * k)) & 255u); }   // v_cvt_f32_ubyte<k>
+
+// Tests the four children of a node; returns the mask of those entered no farther than best_t.
+__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, V3 o, V3 inv, float best_t, float dist[4]) {
+  const float ox = __uint_as_float(A.x), oy = __uint_as_float(A.y), oz = __uint_as_float(A.z);
+  const float sx = __uint_as_float(B.x), sy = __uint_as_float(B.y), sz = __uint_as_float(B.z);
+  // the plane entered first is `hi` for a negative direction (slab(): same rule, so the comparison stays plane by plane)
+  const unsigned nxw = inv.x < 0.0f ? C.w : C.x, fxw = inv.x < 0.0f ? C.x : C.w;
+  const unsigned nyw = inv.y < 0.0f ? D.x : C.y, fyw = inv.y < 0.0f ? C.y : D.x;
+  const unsigned nzw = inv.z < 0.0f ? D.y : C.z, fzw = inv.z < 0.0f ? C.z : D.y;
+  unsigned mask = 0;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float nx = __builtin_fmaf(ubyte_f(nxw, k), sx, ox), fx = __builtin_fmaf(ubyte_f(fxw, k), sx, ox);
+    const float ny = __builtin_fmaf(ubyte_f(nyw, k), sy, oy), fy = __builtin_fmaf(ubyte_f(fyw, k), sy, oy);
+    const float nz = __builtin_fmaf(ubyte_f(nzw, k), sz, oz), fz = __builtin_fmaf(ubyte_f(fzw, k), sz, oz);
+    const float t0x = (nx - o.x) * inv.x, t1x = (fx - o.x) * inv.x;
+    const float t0y = (ny - o.y) * inv.y, t1y = (fy - o.y) * inv.y;
+    const float t0z = (nz - o.z) * inv.z, t1z = (fz - o.z) * inv.z;
+    const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0x, 0.0f), t0y), t0z);
+    const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fminf(t1x, 10000.0f), t1y), t1z);
+    dist[k] = t_min;
+    mask |= (t_max > t_min && t_min <= best_t) ? (1u << k) : 0u;
+  }
+  return mask & (B.w & 15u);
+}
+
+// next record of this lane: the lowest pending child of the newest stack word, or -1 when nothing is left
+__device__ __forceinline__ void wide_pop(Trav& tr, WideStack& ws, const int* __restrict__ stack) {
+  if (ws.top == 0u) {
+    if (ws.sp == 0) { tr.node = -1; return; }
+    ws.sp--;
+    ws.top = (unsigned)stack[ws.sp * 64];
+  }
+  const int j = __builtin_ctz(ws.top);                       // the pending mask is never empty in a stored word
+  tr.node = (int)((((ws.top >> 8) + (unsigned)j) << 1) | ((ws.top >> (4 + j)) & 1u));
+  ws.top &= ws.top - 1u;
+  ws.top = (ws.top & 15u) ? ws.top : 0u;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void wide_node_step(WalkRsrc wide, V3 o, V3 inv, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
+  const unsigned off = (unsigned)(tr.node >> 1) << 6;
+  const u32x4 A = ld_unit_raw(wide, off), B = ld_unit_raw(wide, off + 16), C = ld_unit_raw(wide, off + 32), D = ld_unit_raw(wide, off + 48);
+  if (COUNT) c.V++;
+  float dist[4];
+  const unsigned mask = wide_node_test(A, B, C, D, o, inv, tr.best_t, dist);
+  if (mask != 0u) {
+    // nearest entered child next; the others wait as one stack word
+    const float d0 = (mask & 1u) ? dist[0] : __builtin_inff(), d1 = (mask & 2u) ? dist[1] : __builtin_inff();
+    const float d2 = (mask & 4u) ? dist[2] : __builtin_inff(), d3 = (mask & 8u) ? dist[3] : __builtin_inff();
+    const int n01 = d1 < d0 ? 1 : 0, n23 = d3 < d2 ? 3 : 2;
+    const int near = __builtin_fminf(d2, d3) < __builtin_fminf(d0, d1) ? n23 : n01;
+    const unsigned base = A.w & 0xffffffu, leafmask = (B.w >> 4) & 15u;
+    const unsigned rest = mask & ~(1u << near);
+    if (rest != 0u) {
+      if (ws.top != 0u) { if (ws.sp < WIDE_STACK) { stack[ws.sp * 64] = (int)ws.top; ws.sp++; } }   // the host bounds the depth; the guard only protects LDS
+      ws.top = (base << 8) | (leafmask << 4) | rest;
+    }
+    tr.node = (int)(((base + (unsigned)near) << 1) | ((leafmask >> near) & 1u));
+  } else {
+    wide_pop(tr, ws, stack);
+  }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ void wide_leaf_step(WalkRsrc wide, V3 o, V3 d, V3 inv, Trav& tr, WideStack& ws, const int* __restrict__ stack, Ctr& c) {
+  const unsigned off = (unsigned)(tr.node >> 1) << 6;
+  const float4 A = ld_unit(wide, off), B = ld_unit(wide, off + 16), C = ld_unit(wide, off + 32), D = ld_unit(wide, off + 48);
+  if (COUNT) c.V++;
+  float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
+  float dist;
+  if (slab(o, inv, mn, mx, dist) && dist <= tr.best_t) {      // <=: a box entered exactly at the best t may hold a tie with a lower slot
+    if (COUNT) c.L++;
+    const int info = __float_as_int(A.w);
+    const float t = prim_hit_kind((info >> WALK_SLOT_BITS) & 3, mk(B.w, C.x, C.y), mk(C.z, C.w, D.x), mk(D.y, D.z, D.w), o, d);
+    const int slot = info & ((1 << WALK_SLOT_BITS) - 1);
+    if (t > 0.0f && (t < tr.best_t || (t == tr.best_t && (unsigned)slot < (unsigned)tr.best_slot))) { tr.best_t = t; tr.best_slot = slot; }
+  }
+  wide_pop(tr, ws, stack);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [word * 64] */) {
+  Trav tr;
+  trav_begin(tr);
+  WideStack ws; ws.top = 0u; ws.sp = 0;
+  const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  if (COUNT) c.rays++;
+  while (tr.node >= 0) {
+    if (tr.node & 1) wide_leaf_step<COUNT>(wide, o, d, inv, tr, ws, stack, c);
+    else wide_node_step<COUNT>(wide, o, inv, tr, ws, stack, c);
+  }
+  Hit best; best.t = tr.best_slot < 0 ? -1.0f : tr.best_t; best.slot = tr.best_slot;
+  return best;
 }
 
 __device__ __forceinline__ bool first_active_lane() { return __lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u; }

@@ -34,6 +34,17 @@ constexpr int WALK_UNITS_LEAF = 4;
 constexpr int WALK_SLOT_BITS = 26;                    // slots < 2^26 (the walk array itself is limited to 2^28 units)
 constexpr int WALK_KIND_SPHERE = 0, WALK_KIND_TRIANGLE = 1, WALK_KIND_NONE = 2;   // object type 0 / 2 / anything else
 
+// Wide walk (wide_builder.cpp): 64-byte records, a 4-way tree over the same leaves.
+//   node  {origin.xyz, 0x80000000 | index of first child} {scale.xyz, valid mask | leaf mask << 4}
+//         {lo.x, lo.y, lo.z, hi.x} {hi.y, hi.z, -, -}   each lo/hi word = one byte per child: plane = fmaf(byte, scale, origin)
+//   leaf  {min.xyz, slot | kind << 26} {max.xyz, v0.x} {v0.yz, e1.xy} {e1.z, e2.xyz}      (the walk array's leaf record)
+// A node's children are contiguous records.  The kernel keeps, per lane, the children of a node that were entered
+// but not yet visited as ONE stack word: first child's index << 8 | leaf mask << 4 | pending mask.
+constexpr int WIDE_UNITS = 4;
+constexpr int WIDE_INDEX_BITS = 24;                   // records < 2^24 (1 GiB of them)
+constexpr int WIDE_STACK = 16;                        // stack words per lane kept in LDS (one more lives in a register)
+constexpr int WIDE_MAX_DEPTH = WIDE_STACK + 1;        // most nodes on a root-to-leaf path the kernel can walk
+
 // Ordered traversal: record k describes the two children of internal node k (pre-order index
 // of the internal node among ALL nodes is kept in `DevNode`; pairs are indexed by node id).
 struct DevPair {       // 64 B, 64-B aligned
@@ -88,6 +99,9 @@ struct RenderParams {
   const DevUnit* walk;
   uint32_t walk_bytes;            // size of the walk array (buffer descriptor range; < 4 GiB)
   uint32_t pad_;
+  const DevUnit* wide;            // wide walk records (null: scene not representable, threaded walk is used)
+  uint32_t wide_bytes;
+  uint32_t pad2_;
   const DevPair* pairs;
   const DevPrim* prims;
   const DevShade* shade;

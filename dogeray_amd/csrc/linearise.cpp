@@ -5,10 +5,21 @@
 
 namespace dr {
 
-int linearise(const HostScene& sc, DeviceImage& img) {
+int linearise(const HostScene& sc, DeviceImage& img, int wide_tree_mode) {
   const int N = sc.n;
-  if (sc.bvh.empty() || sc.bvh_used != 2 * N - 1) { set_error("BVH not built"); return DR_ERR_INVALID; }
+  if (N < 2) { set_error("scene needs at least 2 objects (K:1756)"); return DR_ERR_SCENE; }
+  if (sc.bvh.empty() || sc.bvh_used != 2 * N - 1 || (int)sc.objects.size() < N) { set_error("BVH not built"); return DR_ERR_INVALID; }
   const int used = sc.bvh_used;
+  // arrays that came from a caller or from a .rtsb file are not trusted: every link must stay inside the array
+  for (const dr_bvh_node& b : sc.bvh) {
+    if (!b.active) continue;
+    const int lim = (int)sc.bvh.size();
+    if (b.hit_node < -1 || b.hit_node >= lim || b.miss_node < -1 || b.miss_node >= lim ||
+        (!b.end && (b.children[0] < 0 || b.children[0] >= lim || b.children[1] < 0 || b.children[1] >= lim))) {
+      set_error("corrupt BVH (link outside the node array)");
+      return DR_ERR_INVALID;
+    }
+  }
   img.pairs.assign((size_t)(N - 1), DevPair());
   img.prims.assign((size_t)N, DevPrim());
   img.shade.assign((size_t)N, DevShade());
@@ -159,6 +170,22 @@ int linearise(const HostScene& sc, DeviceImage& img) {
         u[2].f[0] = p.v0[1]; u[2].f[1] = p.v0[2]; u[2].f[2] = p.e1x; u[2].f[3] = p.e1y;
         u[3].f[0] = p.e1z; u[3].f[1] = p.e2x; u[3].f[2] = p.e2y; u[3].f[3] = p.e2z;
       }
+    }
+  }
+
+  // the wide walk: a 4-way tree over the same leaves (wide_builder.cpp); scenes it cannot represent keep the threaded walk
+  {
+    std::vector<int> leaf_node_of_slot((size_t)N, -1);
+    for (int k = 0; k < used; k++) {
+      const int ref = order[(size_t)k];
+      if (sc.bvh[(size_t)ref].end) leaf_node_of_slot[(size_t)slot_of[(size_t)ref]] = ref;
+    }
+    WideImage w;
+    img.wide.clear(); img.wide_depth = 0; img.wide_nodes = 0;
+    if (wide_tree_mode >= 0 && build_wide(sc, leaf_node_of_slot, img.prims, wide_tree_mode, 0, w)) {
+      img.wide.swap(w.rec);
+      img.wide_depth = w.depth;
+      img.wide_nodes = w.nodes;
     }
   }
 

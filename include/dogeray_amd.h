@@ -138,11 +138,16 @@ int dr_context_upload_scene(dr_context* c, const dr_scene* s);
  * columns bx with bx % mod == rem; other pixels stay 0.  Default (1, 0) = everything. */
 int dr_context_set_stripe(dr_context* c, int mod, int rem);
 
-/* Traversal used by the megakernel.  Both return the same closest hit as hit() K:468-512.
- *   DR_TRAVERSAL_THREADED  the reference's order: hit/miss links, child 0 first
+/* Traversal used by the megakernel.  All return the same closest hit as hit() K:468-512.
+ *   DR_TRAVERSAL_THREADED  the reference's order: hit/miss links, child 0 first (its visit counters are the
+ *                          reference's: dr_stats.node_visits / prim_tests equal the oracle's V / L)
  *   DR_TRAVERSAL_ORDERED   near child first with a short per-lane stack, ties resolved to the
- *                          leaf the reference order would have reached first            */
-enum { DR_TRAVERSAL_THREADED = 0, DR_TRAVERSAL_ORDERED = 1 };
+ *                          leaf the reference order would have reached first
+ *   DR_TRAVERSAL_WIDE      (default) a 4-way tree with 8-bit child boxes over the reference's own leaves, nearest
+ *                          entered child first, per-lane stack in LDS; the leaves keep the reference's exact boxes
+ *                          and tie order.  A scene it cannot represent (non-finite boxes, > 2^24 records) is walked
+ *                          THREADED; dr_context_get_option("traversal") tells which one launches use.         */
+enum { DR_TRAVERSAL_THREADED = 0, DR_TRAVERSAL_ORDERED = 1, DR_TRAVERSAL_WIDE = 2 };
 int dr_context_set_traversal(dr_context* c, int mode);
 
 /* Tuning knobs of the render kernels; none of them changes a pixel.
@@ -158,10 +163,13 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   reordered, -1: every tile by cost)
  *   "coop_steps"    once the tile queue is empty, a ray older than this many node steps is finished by all 64
  *                   lanes of its wave together (default 64, 0 = off), in waves with at most "coop_lanes" (8) lanes walking
+ *   "wide_tree"     tree under the wide walk, read at dr_context_upload_scene: 1 (default) binned surface-area
+ *                   heuristic over the leaf boxes, 0 the reference's own topology (K:1745-1861) collapsed 4-way
  * The environment variable DOGERAY_OPTIONS="name=value,..." applies the same at context creation. */
 enum { DR_KERNEL_TILE = 0, DR_KERNEL_PERSISTENT = 1 };
 int dr_context_set_option(dr_context* c, const char* name, int value);
-/* Read a knob back (same names), or "tree_depth" of the uploaded scene. */
+/* Read a knob back (same names), or of the uploaded scene: "tree_depth" (reference tree), "wide_depth" / "wide_nodes"
+ * (wide walk; 0 = not representable), "traversal" (the one launches really use). */
 int dr_context_get_option(const dr_context* c, const char* name, int* value);
 
 /* One CudaStarter call.  settings13 = { cam.xyz, look.xyz, aperture, focus, fov, max_depth,

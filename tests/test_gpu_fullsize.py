@@ -75,10 +75,13 @@ def test_frame_properties(big):
     assert not np.array_equal(a, ctx.render_frame(st, W, H, s.background, seed + 1))  # and the seed matters
     ctx.set_option("kernel", 0)
     assert np.array_equal(a, ctx.render_frame(st, W, H, s.background, seed))          # per-tile kernel: same frame
-    ctx.set_traversal(1)
-    assert np.array_equal(a, ctx.render_frame(st, W, H, s.background, seed))          # ordered traversal: same frame
-    ctx.set_traversal(0)
+    for mode in (1, 0):
+        ctx.set_traversal(mode)
+        assert np.array_equal(a, ctx.render_frame(st, W, H, s.background, seed))      # ordered / threaded traversal (tile kernel): same frame
     ctx.set_option("kernel", 1)
+    assert np.array_equal(a, ctx.render_frame(st, W, H, s.background, seed))          # threaded walk, persistent kernel
+    ctx.set_traversal(2)
+    assert ctx.get_option("traversal") == 2 and 10 <= ctx.get_option("wide_depth") <= 17
     # stripes of 8 ranks compose to the full frame
     total = np.zeros_like(a)
     for r in range(8):
@@ -117,12 +120,16 @@ def test_sampled_columns_match_the_oracle(big):
     mod = 24
     ref, rc = osc.render(st, W, H, s.background, seed, nthreads=os.cpu_count() or 8, col_mod=mod, col_rem=5)
     ctx.set_stripe(mod, 5)
+    wide = ctx.render_frame(st, W, H, s.background, seed)          # the default traversal (wide walk)
+    ctx.set_traversal(0)                                           # threaded walk: its counters are the reference's
     ctx.enable_counters(True)
     ctx.stats_reset()
     got = ctx.render_frame(st, W, H, s.background, seed)
     stats = ctx.stats()
     ctx.enable_counters(False)
+    ctx.set_traversal(2)
     ctx.set_stripe(1, 0)
+    assert np.array_equal(wide, got)
     same = float(np.all(got == ref, axis=2).mean())
     print("sampled columns: %.6f of pixels identical; %d rays" % (same, rc["rays"]))
     assert same == 1.0
@@ -146,9 +153,10 @@ def test_other_configs_full_size(other_scenes, synth, name, gen_args, Wc, Hc, te
     a = ctx.render_frame(st, Wc, Hc, s.background, 31337)
     ctx.set_option("kernel", 0)
     assert np.array_equal(a, ctx.render_frame(st, Wc, Hc, s.background, 31337))
-    ctx.set_traversal(1)
-    assert np.array_equal(a, ctx.render_frame(st, Wc, Hc, s.background, 31337))
-    ctx.set_traversal(0)
+    for mode in (1, 0):
+        ctx.set_traversal(mode)
+        assert np.array_equal(a, ctx.render_frame(st, Wc, Hc, s.background, 31337))
+    ctx.set_traversal(2)
     ctx.set_option("kernel", 1)
     ctx.accum_reset(Wc, Hc)
     ctx.render_accumulate(st, Wc, Hc, s.background, 31337, 1000003, 4)
