@@ -323,6 +323,9 @@ def main():
         },
         "setup_s": {"parse": t_parse, "bvh_build": t_bvh, "upload": t_upload},
         "diag": own.get("diag"),
+        # timed launches: sum of wave lifetimes in shader cycles and in 100 MHz ticks -> clock held, mean wave lifetime
+        "timed_waves": {"shader_clock_mhz": 100.0 * timed["diag"][0] / max(1, timed["diag"][7]),
+                        "wave_cycles_per_frame": timed["diag"][0] / max(1, timed["frames"])},
         "simd_efficiency": {"node_loop": ref_order["node_visits"] / max(1, ref_order["trav_slots"]),
                             "bounce_loop": ref_order["rays"] / max(1, ref_order["ray_slots"])},
     }

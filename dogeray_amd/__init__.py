@@ -58,7 +58,7 @@ class DrSettings(C.Structure):
 class DrStats(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("launches", C.c_uint64), ("samples", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64),
                 ("prim_tests", C.c_uint64), ("shades", C.c_uint64), ("texels", C.c_uint64), ("kernel_ms", C.c_double),
-                ("trav_slots", C.c_uint64), ("ray_slots", C.c_uint64), ("diag", C.c_uint64 * 4)]
+                ("trav_slots", C.c_uint64), ("ray_slots", C.c_uint64), ("diag", C.c_uint64 * 8)]
 
     def as_dict(self):
         d = {k: getattr(self, k) for k, _ in self._fields_}

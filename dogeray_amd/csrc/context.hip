@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
     } else if (MODE == DR_TRAVERSAL_WIDE) {
       const WalkRsrc wide = wide_rsrc(P);
       int* stack = lds_stack + wave * (WIDE_STACK * 64) + lane;
-      auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_wide<COUNT>(wide, o, d, cc, stack); };
+      auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_wide<COUNT>(wide, P.wide_pmax, o, d, cc, stack); };
       render_pixel<COUNT>(P, closest, x, y, c);
     } else {
       const WalkRsrc walk = walk_rsrc(P);
@@ -115,6 +115,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   Trav tr; tr.node = -2; tr.best_t = 0; tr.best_slot = -1;
   Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
   V3 inv = mk(0, 0, 0), color = mk(0, 0, 0);
+  WideRay wr; wr.inv = wr.marg = mk(0, 0, 0);   // WIDE: clamped 1/direction and margins of the folded node test, a function of the lane's ray
   Xorwow rng; rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = rng.d = 0;
   int px = -1, py = 0, sample = 0, bounce = 0;
   int frame = 0;                   // frame of the batch the pixel in this slot belongs to
@@ -124,8 +125,10 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   const bool degenerate = P.max_depth <= 0 || !(P.spp_f > 0.0f);
 
   // diagnostic stamps (counting build only): wave lifetime, cycles inside the shade/refill phase
-  unsigned long long t_begin = 0, t_phase = 0, n_iter = 0, n_phase = 0;
-  if (COUNT) t_begin = __builtin_readcyclecounter();
+  unsigned long long t_begin = 0, t_phase = 0, n_iter = 0, n_phase = 0, n_nodestep = 0, n_leafstep = 0, n_shaded = 0;
+  unsigned long long r_begin = 0;
+  // wave lifetime in shader cycles and in 100 MHz ticks, every build: two clock reads per wave, written to the statistics buffer only
+  t_begin = __builtin_readcyclecounter(); r_begin = __builtin_amdgcn_s_memrealtime();
   ParkedLeaf pk; pk.v0x = 0; pk.C = pk.D = u32x4{0, 0, 0, 0}; pk.info = 0; pk.parked = false;   // PARK_MIN > 0 only
   for (;;) {
     const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
@@ -134,6 +137,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       unsigned long long t0 = 0;
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
       const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked);
+      if (COUNT) n_shaded += __popcll(__ballot(shade_me));
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
       float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? WIDE_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
       if (WIDE) {
@@ -274,6 +278,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         ws.top = __float_as_uint(st[0 * 64]); ws.sp = __float_as_int(st[1 * 64]);
         inv = mk(st[11 * 64], st[12 * 64], st[13 * 64]);
         if (fresh_ray) { inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z); ws.top = 0u; ws.sp = 0; }
+        wr = wide_ray(path.rayo, inv, P.wide_pmax);            // recomputed for every lane (a dozen instructions) rather than stashed
       } else {
         asm volatile("" ::: "memory");
         pk.v0x = st[0 * 64]; pk.C = u32x4{__float_as_uint(st[1 * 64]), __float_as_uint(st[2 * 64]), __float_as_uint(st[3 * 64]), __float_as_uint(st[4 * 64])};
@@ -308,21 +313,26 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
     }
     if (WIDE) {
-      // ---- leaf records (exact box + primitive) once enough lanes stand at one, or nobody can take a node step
+      // ---- one record per walking lane.  Lanes at a leaf (exact box + primitive: the long block) wait until enough of
+      // them stand at one, or nobody can take a node step; when they go, they fetch together with the lanes at nodes, so
+      // the wave waits for one round trip, not two.
       const bool at_leaf = tr.node >= 0 && (tr.node & 1);
       const unsigned long long leaves = __ballot(at_leaf);
       const unsigned long long nodes = __ballot(tr.node >= 0 && !(tr.node & 1));
-      if (leaves != 0ull && ((int)__popcll(leaves) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes == 0ull || cur_tile >= ntiles)) {
-        if (at_leaf) {
-          if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
-          wide_leaf_step<COUNT>(walk, path.rayo, path.raydir, inv, tr, ws, my_stack, c);
-          steps++;
-        }
+      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes == 0ull || cur_tile >= ntiles);
+      if (COUNT) { n_leafstep += do_leaves; n_nodestep += nodes != 0ull; }
+      if (tr.node >= 0 && (!at_leaf || do_leaves)) {
+        if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
+        const WideRec r = wide_fetch(walk, tr.node);
+        if (at_leaf) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, tr, ws, my_stack, c);
+        else wide_node_compute<COUNT>(r, path.rayo, inv, wr, tr, ws, my_stack, c);
+        steps++;
       }
-      for (int u = 0; u < P_UNROLL; u++) {
+      for (int u = 1; u < P_UNROLL; u++) {
+        if (COUNT) n_nodestep += __ballot(tr.node >= 0 && !(tr.node & 1)) != 0ull;
         if (tr.node >= 0 && !(tr.node & 1)) {
           if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
-          wide_node_step<COUNT>(walk, path.rayo, inv, tr, ws, my_stack, c);
+          wide_node_step<COUNT>(walk, path.rayo, inv, wr, tr, ws, my_stack, c);
           steps++;
         }
       }
@@ -352,11 +362,17 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
     }
   }
-  if (COUNT && lane == 0) {
+  if (lane == 0) {
     atomicAdd(&P.counters[8], __builtin_readcyclecounter() - t_begin);
+    atomicAdd(&P.counters[15], __builtin_amdgcn_s_memrealtime() - r_begin);      // 100 MHz ticks: wave cycles / this = shader clock / 100 MHz
+  }
+  if (COUNT && lane == 0) {
     atomicAdd(&P.counters[9], t_phase);
     atomicAdd(&P.counters[10], n_iter);
     atomicAdd(&P.counters[11], n_phase);
+    atomicAdd(&P.counters[12], n_nodestep);
+    atomicAdd(&P.counters[13], n_leafstep);
+    atomicAdd(&P.counters[14], n_shaded);
   }
   if (COUNT) {
     unsigned v[8] = {c.rays, c.V, c.L, c.S, c.T, c.samples, c.trav_slots, c.ray_slots};
@@ -509,7 +525,7 @@ __global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, con
     h = closest_hit_ordered<true>(P.pairs, P.prims, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
   } else if (MODE == DR_TRAVERSAL_WIDE) {
     int* stack = lds_stack + (threadIdx.x >> 6) * (WIDE_STACK * 64) + (threadIdx.x & 63);
-    h = closest_hit_wide<true>(wide_rsrc(P), ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
+    h = closest_hit_wide<true>(wide_rsrc(P), P.wide_pmax, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
   } else {
     h = closest_hit_threaded<true>(walk_rsrc(P), ld3(o + 3 * i), ld3(d + 3 * i), c);
   }
@@ -528,7 +544,7 @@ struct dr_context {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   // resident scene
   DevUnit* walk = nullptr; size_t walk_bytes = 0;
-  DevUnit* wide = nullptr; size_t wide_bytes = 0; int wide_depth = 0, wide_nodes = 0;   // null: scene not representable (threaded walk is used)
+  DevUnit* wide = nullptr; size_t wide_bytes = 0; int wide_depth = 0, wide_nodes = 0; float wide_pmax = 0;   // null: scene not representable (threaded walk is used)
   int wide_tree = 1;        // structure of the wide walk's tree: 1 binned SAH (default), 0 the reference's topology collapsed
   DevPair* pairs = nullptr;
   DevPrim* prims = nullptr;
@@ -624,7 +640,7 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   memset(&P, 0, sizeof(P));
   memcpy(c->cur_settings, st, sizeof(c->cur_settings));
   P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims; P.shade = c->shade; P.tex = c->tex; P.texels = c->texels;
-  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes;
+  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax;
   P.counters = c->counters;
   float aspect = float(W / st[11]) / float(H / st[11]);           // K:1016 (int / float)
   float fov = (float)((double)st[8] * M_PI / 180);                // K:1020
@@ -905,7 +921,7 @@ int dr_context_upload_scene(dr_context* c, const dr_scene* s) {
   if ((rc = upload(c->walk, img.walk)) != DR_OK) return rc;
   c->walk_bytes = img.walk.size() * sizeof(DevUnit);
   if (c->wide) { (void)hipFree(c->wide); c->wide = nullptr; }
-  c->wide_bytes = 0; c->wide_depth = img.wide_depth; c->wide_nodes = img.wide_nodes;
+  c->wide_bytes = 0; c->wide_depth = img.wide_depth; c->wide_nodes = img.wide_nodes; c->wide_pmax = img.wide_pmax;
   if (!img.wide.empty()) {
     if ((rc = upload(c->wide, img.wide)) != DR_OK) return rc;
     c->wide_bytes = img.wide.size() * sizeof(DevUnit);
@@ -1098,7 +1114,7 @@ int dr_stats_get(dr_context* c, dr_stats* out) {
   out->rays = h[0]; out->node_visits = h[1]; out->prim_tests = h[2]; out->shades = h[3]; out->texels = h[4];
   if (c->count) out->samples = h[5];
   out->trav_slots = h[6]; out->ray_slots = h[7];
-  for (int k = 0; k < 4; k++) out->diag[k] = h[8 + k];
+  for (int k = 0; k < 8; k++) out->diag[k] = h[8 + k];
   return DR_OK;
 }
 
@@ -1175,7 +1191,7 @@ int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, i
   RenderParams P;
   memset(&P, 0, sizeof(P));
   P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims;
-  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes;
+  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax;
   dim3 grid((unsigned)((n + 255) / 256)), block(256);
   if (traversal_of(c) == DR_TRAVERSAL_WIDE) hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_WIDE>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p, bv.p);
   else if (c->traversal == DR_TRAVERSAL_ORDERED) hipLaunchKernelGGL((kat_hit_kernel<DR_TRAVERSAL_ORDERED>), grid, block, 0, c->stream, P, n, bo.p, bd.p, bt.p, bs.p, bv.p);

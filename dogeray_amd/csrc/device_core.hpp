@@ -8,6 +8,13 @@
 // contraction, IEEE division and square root.
 #pragma once
 #include <hip/hip_runtime.h>
+// Sensitivity experiments (tools/exp_variant.sh): useless extra work in the wide walk's node step.  All 0 in the product.
+#ifndef DR_PAD_VALU
+#define DR_PAD_VALU 0      // n more VALU instructions per node step
+#endif
+#ifndef DR_PAD_VMEM
+#define DR_PAD_VMEM 0      // n more 16-byte fetches per lane and node step, 64 B past the record each
+#endif
 #include <stdint.h>
 
 #include "device_layout.h"
@@ -376,28 +383,77 @@ struct WideStack { unsigned top; int sp; };
 
 __device__ __forceinline__ float ubyte_f(unsigned w, int k) { return (float)((w >> (8 * k)) & 255u); }   // v_cvt_f32_ubyte<k>
 
-// Tests the four children of a node; returns the mask of those entered no farther than best_t.
-__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, V3 o, V3 inv, float best_t, float dist[4]) {
+// Tests the four children of a node; returns the mask of those the ray may enter no farther than best_t, and the key
+// of the nearest (entry distance bits with the child number in the two lowest bits).
+//
+// Arithmetic (DR_WIDE_FOLD, default): the ray is folded into the node's grid once per node -- a = scale * inv,
+// b = (origin - o) * inv -- and a plane costs one conversion and one fma: t = fma(byte, a, b -/+ m).  The result only
+// has to be CONSERVATIVE with respect to the slab test on the decoded plane p = fmaf(byte, scale, origin), which the
+// host checked to enclose the exact boxes: near planes not later, far planes not earlier than fl(fl(p - o) * inv).
+// Both computations differ from the real number (byte * scale + origin - o) * inv by at most
+//   |inv| * u * (3 P + 2 |o|)   [decode, subtract, multiply]   and   |inv| * u * (2 (P + |o|)) + u |t|   [this one],
+// u = 2^-24, P = the largest |plane coordinate| of the scene's nodes, so m = |inv| * 2^-21 * (P + |o|) covers the sum
+// with a quarter to spare (scale is a power of two in [2^-60, 2^60], so a is exact).
+// Extreme directions.  The folded test uses inv clamped to +-2^60 (WideRay::inv): for a zero direction component slab()
+// computes (p - o) * inf = +-inf, or NaN (ignored) when p == o; (p - o) * 2^60 -/+ m, with m >= 2^20 then, lands on
+// the same side of [0, 10000] for every plane at least m * 2^-60 away from the origin and leaves the nearer ones
+// unconstrained -- a superset again, and such rays (a few per frame: N + random can cancel exactly) are still culled
+// along that axis instead of walking the whole slab.  A NaN or > 2^60-long direction component makes m NaN: every plane of
+// that axis becomes NaN and is ignored by max3 / min3 (the axis is not constrained at all).
+// With DR_WIDE_FOLD 0 the planes are decoded and put through slab()'s own subtract-and-multiply (monotone, no margin).
+#ifndef DR_WIDE_FOLD
+#define DR_WIDE_FOLD 1
+#endif
+struct WideRay { V3 inv, marg; };        // what the folded node test needs of a ray besides its origin
+__device__ __forceinline__ WideRay wide_ray(V3 o, V3 inv, float pmax) {
+  WideRay w;
+  auto one = [pmax](float oa, float ia, float& ic, float& m) {
+    ic = __builtin_fminf(__builtin_fmaxf(ia, -0x1p60f), 0x1p60f);                    // NaN -> -2^60, and the margin below is NaN
+    const float k = __builtin_fmaf(pmax + __builtin_fabsf(oa), 0x1p-21f, 0x1p-40f);
+    const float ai = __builtin_fabsf(ic);
+    m = (ia == ia && ai > 0x1p-60f) ? ai * k : __builtin_nanf("");
+  };
+  one(o.x, inv.x, w.inv.x, w.marg.x); one(o.y, inv.y, w.inv.y, w.marg.y); one(o.z, inv.z, w.inv.z, w.marg.z);
+  return w;
+}
+
+__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, V3 o, V3 inv, V3 marg, float best_t, unsigned& near_key) {   // fold: inv = WideRay::inv
   const float ox = __uint_as_float(A.x), oy = __uint_as_float(A.y), oz = __uint_as_float(A.z);
   const float sx = __uint_as_float(B.x), sy = __uint_as_float(B.y), sz = __uint_as_float(B.z);
   // the plane entered first is `hi` for a negative direction (slab(): same rule, so the comparison stays plane by plane)
   const unsigned nxw = inv.x < 0.0f ? C.w : C.x, fxw = inv.x < 0.0f ? C.x : C.w;
   const unsigned nyw = inv.y < 0.0f ? D.x : C.y, fyw = inv.y < 0.0f ? C.y : D.x;
   const unsigned nzw = inv.z < 0.0f ? D.y : C.z, fzw = inv.z < 0.0f ? C.z : D.y;
-  unsigned mask = 0;
+  const float tcap = __builtin_fminf(best_t, 10000.0f);
+#if DR_WIDE_FOLD
+  const float ax = sx * inv.x, ay = sy * inv.y, az = sz * inv.z;
+  const float bx = (ox - o.x) * inv.x, by = (oy - o.y) * inv.y, bz = (oz - o.z) * inv.z;
+  const float bxn = bx - marg.x, bxf = bx + marg.x, byn = by - marg.y, byf = by + marg.y, bzn = bz - marg.z, bzf = bz + marg.z;
+#endif
+  unsigned mask = 0, key = 0xffffffffu;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
+#if DR_WIDE_FOLD
+    const float t0x = __builtin_fmaf(ubyte_f(nxw, k), ax, bxn), t1x = __builtin_fmaf(ubyte_f(fxw, k), ax, bxf);
+    const float t0y = __builtin_fmaf(ubyte_f(nyw, k), ay, byn), t1y = __builtin_fmaf(ubyte_f(fyw, k), ay, byf);
+    const float t0z = __builtin_fmaf(ubyte_f(nzw, k), az, bzn), t1z = __builtin_fmaf(ubyte_f(fzw, k), az, bzf);
+#else
     const float nx = __builtin_fmaf(ubyte_f(nxw, k), sx, ox), fx = __builtin_fmaf(ubyte_f(fxw, k), sx, ox);
     const float ny = __builtin_fmaf(ubyte_f(nyw, k), sy, oy), fy = __builtin_fmaf(ubyte_f(fyw, k), sy, oy);
     const float nz = __builtin_fmaf(ubyte_f(nzw, k), sz, oz), fz = __builtin_fmaf(ubyte_f(fzw, k), sz, oz);
     const float t0x = (nx - o.x) * inv.x, t1x = (fx - o.x) * inv.x;
     const float t0y = (ny - o.y) * inv.y, t1y = (fy - o.y) * inv.y;
     const float t0z = (nz - o.z) * inv.z, t1z = (fz - o.z) * inv.z;
-    const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0x, 0.0f), t0y), t0z);
-    const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fminf(t1x, 10000.0f), t1y), t1z);
-    dist[k] = t_min;
-    mask |= (t_max > t_min && t_min <= best_t) ? (1u << k) : 0u;
+#endif
+    const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0x, t0y), t0z), 0.0f);
+    const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fminf(t1x, t1y), t1z), tcap);
+    // >= where slab() has > and <=: a superset, which is all an internal node needs
+    const bool pass = t_max >= t_min;
+    mask |= pass ? (1u << k) : 0u;
+    const unsigned kk = pass ? ((__float_as_uint(t_min) & ~3u) | (unsigned)k) : 0xffffffffu;   // t_min >= 0: its bits order like the value
+    key = kk < key ? kk : key;
   }
+  near_key = key;
   return mask & (B.w & 15u);
 }
 
@@ -414,20 +470,37 @@ __device__ __forceinline__ void wide_pop(Trav& tr, WideStack& ws, const int* __r
   ws.top = (ws.top & 15u) ? ws.top : 0u;
 }
 
+// One record = four 16-byte units, fetched together whatever the record is (a lane learns from the parent's leaf
+// mask, not from the record, whether it is a leaf).  The empty asm pins all four loads in front of the first
+// use: without it hipcc sinks the leaf's primitive units behind the box test, a second dependent round trip.
+struct WideRec { u32x4 A, B, C, D; };
+__device__ __forceinline__ WideRec wide_fetch(WalkRsrc wide, int node) {
+  const unsigned off = (unsigned)(node >> 1) << 6;
+  WideRec r;
+  r.A = ld_unit_raw(wide, off); r.B = ld_unit_raw(wide, off + 16); r.C = ld_unit_raw(wide, off + 32); r.D = ld_unit_raw(wide, off + 48);
+#if DR_PAD_VMEM
+  { u32x4 padm[DR_PAD_VMEM];
+    _Pragma("unroll") for (int k = 0; k < DR_PAD_VMEM; k++) padm[k] = ld_unit_raw(wide, off + 64u * (unsigned)(k + 1));
+    _Pragma("unroll") for (int k = 0; k < DR_PAD_VMEM; k++) asm volatile("" :: "v"(padm[k])); }
+#endif
+  asm volatile("" : "+v"(r.A), "+v"(r.B), "+v"(r.C), "+v"(r.D));
+  return r;
+}
+
 template <bool COUNT>
-__device__ __forceinline__ void wide_node_step(WalkRsrc wide, V3 o, V3 inv, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
-  const unsigned off = (unsigned)(tr.node >> 1) << 6;
-  const u32x4 A = ld_unit_raw(wide, off), B = ld_unit_raw(wide, off + 16), C = ld_unit_raw(wide, off + 32), D = ld_unit_raw(wide, off + 48);
+__device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv, const WideRay& wr, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
   if (COUNT) c.V++;
-  float dist[4];
-  const unsigned mask = wide_node_test(A, B, C, D, o, inv, tr.best_t, dist);
+#if DR_PAD_VALU
+  _Pragma("unroll") for (int k = 0; k < DR_PAD_VALU; k++) asm volatile("v_or_b32 %0, 0, %0" : "+v"(tr.best_slot));
+#endif
+  unsigned key;
+  const unsigned mask = wide_node_test(r.A, r.B, r.C, r.D, o, DR_WIDE_FOLD ? wr.inv : inv, wr.marg, tr.best_t, key);
   if (mask != 0u) {
-    // nearest entered child next; the others wait as one stack word
-    const float d0 = (mask & 1u) ? dist[0] : __builtin_inff(), d1 = (mask & 2u) ? dist[1] : __builtin_inff();
-    const float d2 = (mask & 4u) ? dist[2] : __builtin_inff(), d3 = (mask & 8u) ? dist[3] : __builtin_inff();
-    const int n01 = d1 < d0 ? 1 : 0, n23 = d3 < d2 ? 3 : 2;
-    const int near = __builtin_fminf(d2, d3) < __builtin_fminf(d0, d1) ? n23 : n01;
-    const unsigned base = A.w & 0xffffffu, leafmask = (B.w >> 4) & 15u;
+    // nearest entered child next; the others wait as one stack word.  An unused child slot (inverted box, valid bit
+    // clear) can only pass on a degenerate grid or ray; if it even has the smallest key, take the lowest valid one.
+    int near = (int)(key & 3u);
+    near = ((mask >> near) & 1u) ? near : __builtin_ctz(mask);
+    const unsigned base = r.A.w & 0xffffffu, leafmask = (r.B.w >> 4) & 15u;
     const unsigned rest = mask & ~(1u << near);
     if (rest != 0u) {
       if (ws.top != 0u) { if (ws.sp < WIDE_STACK) { stack[ws.sp * 64] = (int)ws.top; ws.sp++; } }   // the host bounds the depth; the guard only protects LDS
@@ -440,16 +513,15 @@ __device__ __forceinline__ void wide_node_step(WalkRsrc wide, V3 o, V3 inv, Trav
 }
 
 template <bool COUNT>
-__device__ __forceinline__ void wide_leaf_step(WalkRsrc wide, V3 o, V3 d, V3 inv, Trav& tr, WideStack& ws, const int* __restrict__ stack, Ctr& c) {
-  const unsigned off = (unsigned)(tr.node >> 1) << 6;
-  const float4 A = ld_unit(wide, off), B = ld_unit(wide, off + 16), C = ld_unit(wide, off + 32), D = ld_unit(wide, off + 48);
+__device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, V3 inv, Trav& tr, WideStack& ws, const int* __restrict__ stack, Ctr& c) {
+  auto f = [](unsigned v) { return __uint_as_float(v); };
   if (COUNT) c.V++;
-  float mn[3] = {A.x, A.y, A.z}, mx[3] = {B.x, B.y, B.z};
+  float mn[3] = {f(r.A.x), f(r.A.y), f(r.A.z)}, mx[3] = {f(r.B.x), f(r.B.y), f(r.B.z)};
   float dist;
   if (slab(o, inv, mn, mx, dist) && dist <= tr.best_t) {      // <=: a box entered exactly at the best t may hold a tie with a lower slot
     if (COUNT) c.L++;
-    const int info = __float_as_int(A.w);
-    const float t = prim_hit_kind((info >> WALK_SLOT_BITS) & 3, mk(B.w, C.x, C.y), mk(C.z, C.w, D.x), mk(D.y, D.z, D.w), o, d);
+    const int info = (int)r.A.w;
+    const float t = prim_hit_kind((info >> WALK_SLOT_BITS) & 3, mk(f(r.B.w), f(r.C.x), f(r.C.y)), mk(f(r.C.z), f(r.C.w), f(r.D.x)), mk(f(r.D.y), f(r.D.z), f(r.D.w)), o, d);
     const int slot = info & ((1 << WALK_SLOT_BITS) - 1);
     if (t > 0.0f && (t < tr.best_t || (t == tr.best_t && (unsigned)slot < (unsigned)tr.best_slot))) { tr.best_t = t; tr.best_slot = slot; }
   }
@@ -457,15 +529,23 @@ __device__ __forceinline__ void wide_leaf_step(WalkRsrc wide, V3 o, V3 d, V3 inv
 }
 
 template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [word * 64] */) {
+__device__ __forceinline__ void wide_node_step(WalkRsrc wide, V3 o, V3 inv, const WideRay& wr, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
+  const WideRec r = wide_fetch(wide, tr.node);
+  wide_node_compute<COUNT>(r, o, inv, wr, tr, ws, stack, c);
+}
+
+template <bool COUNT>
+__device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, float pmax, V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [word * 64] */) {
   Trav tr;
   trav_begin(tr);
   WideStack ws; ws.top = 0u; ws.sp = 0;
   const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  const WideRay wr = wide_ray(o, inv, pmax);
   if (COUNT) c.rays++;
   while (tr.node >= 0) {
-    if (tr.node & 1) wide_leaf_step<COUNT>(wide, o, d, inv, tr, ws, stack, c);
-    else wide_node_step<COUNT>(wide, o, inv, tr, ws, stack, c);
+    const WideRec r = wide_fetch(wide, tr.node);
+    if (tr.node & 1) wide_leaf_compute<COUNT>(r, o, d, inv, tr, ws, stack, c);
+    else wide_node_compute<COUNT>(r, o, inv, wr, tr, ws, stack, c);
   }
   Hit best; best.t = tr.best_slot < 0 ? -1.0f : tr.best_t; best.slot = tr.best_slot;
   return best;

@@ -101,7 +101,7 @@ struct RenderParams {
   uint32_t pad_;
   const DevUnit* wide;            // wide walk records (null: scene not representable, threaded walk is used)
   uint32_t wide_bytes;
-  uint32_t pad2_;
+  float wide_pmax;                // largest |plane coordinate| of the wide walk's nodes (margin of the folded node test)
   const DevPair* pairs;
   const DevPrim* prims;
   const DevShade* shade;

@@ -17,12 +17,14 @@ struct DeviceImage {
   float root_mn[3], root_mx[3];
   std::vector<DevUnit> wide;       // wide walk records, empty if the scene is not representable
   int wide_depth = 0, wide_nodes = 0;
+  float wide_pmax = 0;
 };
 
 // wide_builder.cpp: the 4-way traversal structure over the reference's leaves (device_layout.h "wide walk")
 struct WideImage {
   std::vector<DevUnit> rec;        // WIDE_UNITS per record, root = record 0
   int depth = 0, nodes = 0, leaves = 0;
+  float pmax = 0;                  // largest |decoded plane coordinate| over all nodes
 };
 // tree_mode 1: binned-SAH tree (default), 0: the reference's topology collapsed.  false = not representable.
 bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, const std::vector<DevPrim>& prims, int tree_mode,

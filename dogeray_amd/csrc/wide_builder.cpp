@@ -222,10 +222,10 @@ bool quantise(const Box* cb, int n, float origin[3], float scale[3], uint8_t lo[
     if (!std::isfinite(o) || !std::isfinite(ext)) return false;
     int e;
     (void)frexpf(ext > 0 ? ext / 255.0f : 0.0f, &e);       // ext / 255 = m * 2^e, m in [0.5, 1): 2^e >= ext / 255
-    if (!(ext > 0)) e = -100;
-    if (e < -100) e = -100;
+    if (!(ext > 0)) e = -60;
+    if (e < -60) e = -60;                                   // scale in [2^-60, 2^60]: scale * (1 / direction) stays exact in the kernel
     for (;; e++) {
-      if (e > 126) return false;
+      if (e > 60) return false;
       const float s = ldexpf(1.0f, e);
       bool ok = true;
       for (int k = 0; k < n && ok; k++) {
@@ -325,6 +325,7 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
   std::vector<Item> st;
   st.push_back({0, 0});
   int n_nodes = 0, n_leaves = 0;
+  float pmax = 0.0f;
   WNode w;
   while (!st.empty()) {
     const Item it = st.back();
@@ -343,6 +344,7 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
     uint8_t lo[4][3], hi[4][3];
     memset(lo, 0, sizeof(lo)); memset(hi, 0, sizeof(hi));
     if (!quantise(cb, w.n, origin, scale, lo, hi)) return false;
+    for (int a = 0; a < 3; a++) pmax = fmaxf(pmax, fmaxf(fabsf(origin[a]), fabsf(fmaf(255.0f, scale[a], origin[a]))));
     uint32_t words[WIDE_UNITS * 4];
     memset(words, 0, sizeof(words));
     for (int a = 0; a < 3; a++) { words[a] = fbits(origin[a]); words[4 + a] = fbits(scale[a]); }
@@ -371,7 +373,7 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
     }
   }
   if (n_leaves != N) return false;
-  out.depth = depth; out.nodes = n_nodes; out.leaves = n_leaves;
+  out.depth = depth; out.nodes = n_nodes; out.leaves = n_leaves; out.pmax = pmax;
   return true;
 }
 

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define DR_ABI_VERSION 1
+#define DR_ABI_VERSION 2
 
 typedef enum dr_status {
   DR_OK = 0,
@@ -206,7 +206,8 @@ typedef struct dr_stats {
   double kernel_ms;       /* sum of HIP-event durations of the render kernel launches   */
   uint64_t trav_slots;    /* 64 x wave-level traversal iterations: node_visits / trav_slots = SIMD efficiency of the node loop */
   uint64_t ray_slots;     /* 64 x wave-level closest-hit calls:    rays / ray_slots = SIMD efficiency of the bounce loop       */
-  uint64_t diag[4];       /* counting build of the persistent kernel: wave cycles, cycles in the shade phase, loop iterations, shade phases */
+  uint64_t diag[8];       /* counting build of the persistent kernel: wave cycles, cycles in the shade phase, loop iterations, shade phases,
+                             wave-level node steps, wave-level leaf steps (wide walk), lanes shaded, wave lifetime in 100 MHz ticks */
 } dr_stats;
 int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the kernel; off by default */
 int dr_stats_reset(dr_context* c);

@@ -197,7 +197,7 @@ def test_library_exports_every_declared_symbol(dr):
     for n in names:
         assert hasattr(L, n), "libdogeray_amd.so does not export %s" % n
     assert sorted(dr.API_SYMBOLS) == names, "python binding and header disagree"
-    assert dr.lib().dr_abi_version() == 1
+    assert dr.lib().dr_abi_version() == 2
 
 
 def test_struct_layouts_match_header(dr):

@@ -12,5 +12,8 @@ d=j.get("diag")
 if d and d[2]:
     fr=j["steps"]
     print("   diag/frame: wave-cycles %.3g  phase-cycles %.3g (%.1f%%)  iters %.3g  phases %.3g  cycles/iter %.0f  cycles/phase %.0f" % (d[0]/fr, d[1]/fr, 100.0*d[1]/max(1,d[0]), d[2]/fr, d[3]/fr, (d[0]-d[1])/max(1,d[2]), d[1]/max(1,d[3])))
+    if len(d) > 6 and d[4]:
+        if len(d) > 7 and d[7]: print("   shader clock while the counting build ran: %.0f MHz" % (100.0 * d[0] / d[7]))
+        print("   wave-level steps/frame: node %.3g  leaf %.3g;  lanes shaded per phase %.1f;  records/ray %.2f  prim tests/ray %.2f" % (d[4]/fr, d[5]/fr, d[6]/max(1,d[3]), j["per_ray"]["kernel"]["V"], j["per_ray"]["kernel"]["L"]))
 PY
 done

@@ -30,11 +30,14 @@ static float tri(const float o[3], const float d[3], const float* v0, const floa
   float t = f*(e2[0]*q[0]+e2[1]*q[1]+e2[2]*q[2]); return t > 1e-4f ? t : -1;
 }
 
-struct WideStats { long nodes = 0, leaves = 0, tests = 0, maxsp = 0; };
+struct WideStats { long nodes = 0, leaves = 0, tests = 0, maxsp = 0, cull_nodes = 0, cull_leaves = 0, cull_entry = 0, extra_children = 0; };
 
-static void wide_hit(const std::vector<DevUnit>& rec, const float o[3], const float d[3], const float inv[3], float& best_t, int& best_slot, WideStats& ws) {
+static void wide_hit(const std::vector<DevUnit>& rec, float pmax, const float o[3], const float d[3], const float inv[3], float& best_t, int& best_slot, WideStats& ws) {
   best_t = 1e7f; best_slot = -1;
+  float marg[3], invc[3];   // wide_ray(): clamped 1/direction and margins of the folded test
+  for (int a = 0; a < 3; a++) { invc[a] = fminf(fmaxf(inv[a], -0x1p60f), 0x1p60f); const float k = fmaf(pmax + fabsf(o[a]), 0x1p-21f, 0x1p-40f), ai = fabsf(invc[a]); marg[a] = (inv[a] == inv[a] && ai > 0x1p-60f) ? ai * k : NAN; }
   unsigned stack[WIDE_STACK]; int sp = 0; unsigned top = 0;
+  float sd[WIDE_STACK + 1][4]; float topd[4] = {0, 0, 0, 0};   // study only: entry distance of every pending child
   unsigned cur = 0;   // index << 1 | leaf
   for (;;) {
     const uint32_t* w = reinterpret_cast<const uint32_t*>(&rec[(size_t)(cur >> 1) * WIDE_UNITS]);
@@ -54,28 +57,42 @@ static void wide_hit(const std::vector<DevUnit>& rec, const float o[3], const fl
     } else {
       ws.nodes++;
       const unsigned base = w[3] & 0xffffffu, valid = w[7] & 15u, leafmask = (w[7] >> 4) & 15u;
-      unsigned mask = 0; float dist[4];
+      // the kernel's folded test (wide_node_test, DR_WIDE_FOLD) and, as a check, the plain decode-and-slab test it must cover
+      unsigned mask = 0, mask_plain = 0, key = 0xffffffffu; float dist[4] = {0, 0, 0, 0};
+      const float tcap = fminf(best_t, 10000.0f);
+      float a3[3], bn[3], bf[3];
+      for (int a = 0; a < 3; a++) { a3[a] = f[4 + a] * invc[a]; const float b = (f[a] - o[a]) * invc[a]; bn[a] = b - marg[a]; bf[a] = b + marg[a]; }
       for (int k = 0; k < 4; k++) {
-        float mn[3], mx[3];
+        float mn[3], mx[3], t0[3], t1[3];
         for (int a = 0; a < 3; a++) {
-          mn[a] = fmaf((float)((w[8 + a] >> (8 * k)) & 255u), f[4 + a], f[a]);
-          mx[a] = fmaf((float)((w[11 + a] >> (8 * k)) & 255u), f[4 + a], f[a]);
+          const float ql = (float)((w[8 + a] >> (8 * k)) & 255u), qh = (float)((w[11 + a] >> (8 * k)) & 255u);
+          mn[a] = fmaf(ql, f[4 + a], f[a]); mx[a] = fmaf(qh, f[4 + a], f[a]);
+          const float qn = inv[a] < 0 ? qh : ql, qf = inv[a] < 0 ? ql : qh;
+          t0[a] = fmaf(qn, a3[a], bn[a]); t1[a] = fmaf(qf, a3[a], bf[a]);
         }
-        if (slab(o, inv, mn, mx, dist[k]) && dist[k] <= best_t) mask |= 1u << k;
+        float dplain;
+        if (slab(o, inv, mn, mx, dplain) && dplain <= best_t) mask_plain |= 1u << k;
+        const float tmin = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), t0[2]), 0.0f), tmax = fminf(fminf(fminf(t1[0], t1[1]), t1[2]), tcap);
+        if (tmax >= tmin) { mask |= 1u << k; uint32_t kb; memcpy(&kb, &tmin, 4); kb = (kb & ~3u) | (unsigned)k; if (kb < key) key = kb; if (dplain < tmin && (mask_plain >> k & 1)) { printf("folded entry distance later than the plain one: %g > %g\n", tmin, dplain); exit(3); } }
+        dist[k] = tmin;
       }
-      mask &= valid;
+      mask &= valid; mask_plain &= valid;
+      if (mask_plain & ~mask) { printf("FOLDED TEST NOT CONSERVATIVE: plain %x folded %x\n", mask_plain, mask); exit(3); }
+      ws.extra_children += __builtin_popcount(mask & ~mask_plain);
       if (mask) {
-        int near = -1;
-        for (int k = 0; k < 4; k++) if ((mask >> k & 1) && (near < 0 || dist[k] < dist[near])) near = k;
+        int near = (int)(key & 3u);
+        if (!((mask >> near) & 1u)) near = __builtin_ctz(mask);
         const unsigned rest = mask & ~(1u << near);
-        if (rest) { if (top) { if (sp >= WIDE_STACK) { printf("STACK OVERFLOW\n"); exit(2); } stack[sp++] = top; } top = (base << 8) | (leafmask << 4) | rest; if (sp > ws.maxsp) ws.maxsp = sp; }
+        if (rest) { if (top) { if (sp >= WIDE_STACK) { printf("STACK OVERFLOW\n"); exit(2); } memcpy(sd[sp], topd, 16); stack[sp++] = top; } top = (base << 8) | (leafmask << 4) | rest; memcpy(topd, dist, 16); if (sp > ws.maxsp) ws.maxsp = sp; }
         cur = ((base + (unsigned)near) << 1) | ((leafmask >> near) & 1u);
         descend = true;
       }
     }
     if (descend) continue;
-    if (!top) { if (sp == 0) break; top = stack[--sp]; }
+    if (!top) { if (sp == 0) break; top = stack[--sp]; memcpy(topd, sd[sp], 16); }
     const int j = __builtin_ctz(top & 15u);
+    if (topd[j] > best_t) { if ((top >> (4 + j)) & 1u) ws.cull_leaves++; else ws.cull_nodes++; }
+    { bool all = true; for (int k = 0; k < 4; k++) if ((top >> k & 1) && !(topd[k] > best_t)) all = false; if (all) ws.cull_entry++; }
     cur = (((top >> 8) + (unsigned)j) << 1) | ((top >> (4 + j)) & 1u);
     top &= top - 1;
     if (!(top & 15u)) top = 0;
@@ -119,16 +136,18 @@ int main(int argc, char** argv) {
               float tt = p.type == 2 ? tri(o, d, p.v0, e1, e2) : -1; if (tt > 0 && tt < 10000.0f && tt < best) { best = tt; bs = slot[node]; } } node = b.miss_node; }
           else { bin_int++; node = h ? b.hit_node : b.miss_node; } } }
       float wb; int wsl;
-      wide_hit(img.wide, o, d, inv, wb, wsl, ws);
+      wide_hit(img.wide, img.wide_pmax, o, d, inv, wb, wsl, ws);
       if (wsl != bs || (bs >= 0 && wb != best)) { printf("MISMATCH ray %d bounce %d: wide %d %g vs reference %d %g\n", r, bounce, wsl, wb, bs, best); return 1; }
       rays++;
       if (bs < 0) break;
       for (int a = 0; a < 3; a++) o[a] += best * d[a];
       float nd[3]; do { nd[0] = 2*U(rng2)-1; nd[1] = 2*U(rng2)-1; nd[2] = 2*U(rng2)-1; } while (nd[0]*nd[0]+nd[1]*nd[1]+nd[2]*nd[2] > 1 || nd[0]*nd[0]+nd[1]*nd[1]+nd[2]*nd[2] < 1e-3f);
-      if (nd[1] > 0) nd[1] = -nd[1]; norm(nd); for (int a = 0; a < 3; a++) { d[a] = nd[a]; o[a] += 1e-3f * nd[a]; }
+      if (nd[1] > 0) nd[1] = -nd[1]; norm(nd);
+      if (r % 50 == 7) nd[(r / 50) % 3] = (r & 64) ? 0.0f : -0.0f;      // exactly axis-parallel components: 1 / 0 = +-inf in slab()
+      if (r % 50 == 9) nd[(r / 50) % 3] = 1e-30f; for (int a = 0; a < 3; a++) { d[a] = nd[a]; o[a] += 1e-3f * nd[a]; }
     }
   }
-  printf("%ld rays, hits identical.  reference walk: %.1f internal + %.1f leaf visits, %.2f primitive tests per ray;  wide walk (tree mode %d): %.1f node + %.1f leaf records, %.2f primitive tests per ray, deepest stack %ld\n",
-         rays, (double)bin_int / rays, (double)bin_leaf / rays, (double)bin_tests / rays, mode, (double)ws.nodes / rays, (double)ws.leaves / rays, (double)ws.tests / rays, ws.maxsp);
+  printf("%ld rays, hits identical.  reference walk: %.1f internal + %.1f leaf visits, %.2f primitive tests per ray;  wide walk (tree mode %d): %.1f node + %.1f leaf records, %.2f primitive tests per ray, deepest stack %ld; fetched although already farther than the best t when popped: %.2f nodes + %.2f leaves per ray; children entered by the folded test only: %.3f per ray\n",
+         rays, (double)bin_int / rays, (double)bin_leaf / rays, (double)bin_tests / rays, mode, (double)ws.nodes / rays, (double)ws.leaves / rays, (double)ws.tests / rays, ws.maxsp, (double)ws.cull_nodes / rays, (double)ws.cull_leaves / rays, (double)ws.extra_children / rays);
   return 0;
 }
