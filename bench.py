@@ -4,10 +4,17 @@
 Workload (BASELINE.json metric; config "highpoly.rts (~1M tris) 1920x1080"): the reference scene is a
 missing blob, so the stand-in SURVEY.md 8(d) specifies is generated: a 709x709-vertex heightfield
 (1 002 528 triangles, 38-column .rts, smooth normals, materials {0,3,5}), 1920x1080, 1 spp per frame,
-depth 10.  A "step" is one full frame = one launch of the megakernel over every pixel.  A "ray" is one
-closest-hit query (one hit() call, kernel.cu K:800).
+depth 10.  A "step" is one full frame (every pixel once).  A "ray" is one closest-hit query (one hit()
+call, kernel.cu K:800).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--repeats R]
+
+What is timed: after W warm-up frames, the K-frame region (inputs resident, barrier + synchronize on
+both sides) is run R times (default 10); `ms_per_step` is the MEDIAN region time / K (min and max are
+reported beside it) and `value` = rays of one region / median time.  The library renders the K frames
+of a region in launches of up to --batch frames (one work queue over all their tiles: BATCHED
+throughput); `single_frame_ms` is the same scene with ONE frame per launch, what the reference's
+present loop does (one CudaStarter call per displayed frame, K:2154-2224).
 
 N > 1 is launched by torch.distributed.run, one rank per GPU; the framebuffer is tiled by interleaved
 8-pixel block columns and gathered to rank 0 over RCCL every --gather-every frames (scaling: strong,
@@ -24,6 +31,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+VALU_PEAK_LANE_OPS = 78.65e12   # 256 CUs x 4 SIMDs x 32 lanes/clk x 2.4 GHz = the 157.3 TFLOP/s fp32 vector peak / 2 flops per fma (same guide)
 
 
 def log(*a):
@@ -73,11 +81,13 @@ def ensure_scene(cache_dir, verts, W, H):
     return path
 
 
-def measure_traffic(args):
-    """HBM-side bytes per render-kernel launch from rocprofv3 PMC counters, each counter in its own pass
-    (MI355X_MICROARCH.md, HBM / rocprofv3 sections): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
-    reports half the bytes of 16-byte-per-lane reads, so it is doubled (calibrated for streaming reads; taken
-    over for this kernel's 16-byte gathers).  Runs this script as a child under rocprofv3; returns None on any problem."""
+def measure_counters(args):
+    """PMC counters of the timed render kernel, per launch, from rocprofv3 child runs of this same command -- each group
+    in its own pass, kernel-trace/stats never combined with --pmc (MI355X_MICROARCH.md, HBM / rocprofv3 sections):
+    FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of 16-byte-per-lane reads, so it
+    is doubled (calibrated for streaming reads; taken over for this kernel's 16-byte gathers).  The SQ pass gives the
+    wave-level VALU instruction count and the active-lane count behind `roofline` (bound: VALU issue).
+    Returns None on any problem."""
     import csv
     import glob
     import shutil
@@ -88,29 +98,33 @@ def measure_traffic(args):
     out = {}
     tmp = tempfile.mkdtemp(prefix="dogeray_pmc_")
     try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            d = os.path.join(tmp, counter)
-            cmd = [prof, "--pmc", counter, "-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
+        for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVES"]):
+            d = os.path.join(tmp, group[0])
+            cmd = [prof, "--pmc"] + group + ["-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                    "--steps", str(args.steps), "--warmup", str(max(args.warmup, args.steps)), "--batch", str(args.batch), "--traversal", args.traversal,
                    "--verts", str(args.verts), "--width", str(args.width), "--height", str(args.height), "--cache", args.cache,
-                   "--no-cpu-baseline", "--no-traffic"]
+                   "--repeats", "1", "--no-cpu-baseline", "--no-traffic", "--no-extras"]
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, env=env, cwd="/tmp")
             if r.returncode != 0:
                 return None
-            vals = []
+            vals = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
                     # the timed launches only: the non-counting build of the render kernel
-                    if row["Counter_Name"] == counter and "render_" in row["Kernel_Name"] and "<false" in row["Kernel_Name"]:
-                        vals.append(float(row["Counter_Value"]))
-            if not vals:
-                return None
-            full = max(vals)                      # launches that cover a full batch report the largest value
-            vals = [v for v in vals if v > 0.8 * full]
-            out[counter] = sum(vals) / len(vals) * 1024.0
-        return {"bytes_per_launch": 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"], "fetch_size_bytes_raw": out["FETCH_SIZE"],
-                "write_size_bytes": out["WRITE_SIZE"]}
+                    if row["Counter_Name"] in group and "render_" in row["Kernel_Name"] and "<false" in row["Kernel_Name"]:
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for name in group:
+                v = vals.get(name)
+                if not v:
+                    return None
+                full = max(v)                         # launches that cover a full batch report the largest value
+                v = [x for x in v if x > 0.8 * full]
+                out[name] = sum(v) / len(v)
+        out["FETCH_SIZE"] *= 1024.0
+        out["WRITE_SIZE"] *= 1024.0
+        out["bytes_per_launch"] = 2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]
+        return out
     except Exception:
         return None
     finally:
@@ -134,8 +148,10 @@ def main():
     ap.add_argument("--traversal", choices=["wide", "threaded", "ordered"], default="wide")
     ap.add_argument("--batch", type=int, default=0, help="frames per kernel launch (default 32 x GPUs, at most 256: a launch has to outlast its longest pixel, ~3 ms)")
     ap.add_argument("--gather-every", type=int, default=0, help="frames between two gathers to rank 0 (default: --batch)")
+    ap.add_argument("--repeats", type=int, default=10, help="how often the K-step timed region is run; the median is reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline.traffic")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes that fill roofline (traffic, VALU counters)")
+    ap.add_argument("--no-extras", action="store_true", help="skip single_frame_ms and the gather-ceiling probe")
     ap.add_argument("--cpu-col-mod", type=int, default=1, help="cpu_baseline renders every n-th block column")
     ap.add_argument("--cache", default=os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"))
     args = ap.parse_args()
@@ -157,8 +173,8 @@ def main():
     if world == 1 and not args.no_traffic and not under_profiler():
         ensure_scene(args.cache, args.verts, args.width, args.height)
         t0 = time.time()
-        traffic_probe = measure_traffic(args)
-        log("traffic probe (2 rocprofv3 passes): %.1f s -> %s" % (time.time() - t0, "ok" if traffic_probe else "unavailable"))
+        traffic_probe = measure_counters(args)
+        log("counter probe (3 rocprofv3 passes): %.1f s -> %s" % (time.time() - t0, "ok" if traffic_probe else "unavailable"))
 
     import torch
     import dogeray_amd as dr
@@ -206,41 +222,86 @@ def main():
 
     seed_base, seed_stride = 1, 1000003
     ctx.accum_reset(W, H)
-    acc = multigpu.accumulator_tensor(ctx, torch.device("cuda", device_index)) if world > 1 else None
+    # N > 1: backend nccl (= RCCL) gathers on the device with the library's pack / unpack kernels, stream-ordered (no host
+    # wait between a batch and its gather); backend gloo (rehearsal on a box with fewer GPUs than ranks) goes through host copies
     coll_dev = "cuda" if backend == "nccl" else "cpu"
-    gatherer = None
+    gatherer = acc = None
     if world > 1:
-        gatherer = multigpu.FrameGatherer(acc if backend == "nccl" else acc.cpu(), W, H, world, rank)
+        if backend == "nccl":
+            gatherer = multigpu.StripeGatherer(ctx, W, H, world, rank, torch.device("cuda", device_index))
+        else:
+            acc = multigpu.accumulator_tensor(ctx, torch.device("cuda", device_index))
+            gatherer = multigpu.FrameGatherer(acc.cpu(), W, H, world, rank)
 
     def run_frames(first, count):
         """Render frames [first, first+count) into the accumulator; gather every --gather-every frames."""
+        if world == 1:
+            ctx.render_accumulate(st, W, H, s.background, seed_base + first * seed_stride, seed_stride, count)
+            return
         k = 0
         while k < count:
-            n = min(args.gather_every, count - k) if world > 1 else count - k
-            ctx.render_accumulate(st, W, H, s.background, seed_base + (first + k) * seed_stride, seed_stride, n)
-            if world > 1:
-                gatherer.gather(acc if backend == "nccl" else acc.cpu())
-                torch.cuda.synchronize()      # the gather reads the accumulator on torch's stream: finish before the next frames write it
+            n = min(args.gather_every, count - k)
+            if backend == "nccl":
+                ctx.render_accumulate_async(st, W, H, s.background, seed_base + (first + k) * seed_stride, seed_stride, n)
+                gatherer.gather_async()
+            else:
+                ctx.render_accumulate(st, W, H, s.background, seed_base + (first + k) * seed_stride, seed_stride, n)
+                gatherer.gather(acc.cpu())
             k += n
+        if backend == "nccl":
+            gatherer.finish()
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- warmup, then the timed region
+    # ---- warmup, then the timed region, `repeats` times (same frames, same seeds: same work every time)
     run_frames(0, args.warmup)
-    ctx.stats_reset()
-    fence()
-    t0 = time.perf_counter()
-    run_frames(args.warmup, args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    timed = ctx.stats()
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    region_s, timed = [], None
+    for rep in range(max(1, args.repeats)):
+        ctx.stats_reset()
+        fence()
+        t0 = time.perf_counter()
+        run_frames(args.warmup, args.steps)
+        fence()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        region_s.append(dt)
+        st_rep = ctx.stats()
+        if timed is None or st_rep["kernel_ms"] < timed["kernel_ms"]:
+            timed = st_rep                       # launch statistics of the fastest repeat (HIP events, clock stamps)
+    srt = sorted(region_s)
+    elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+
+    # ---- one frame per launch (the reference's call pattern), same frames
+    single = None
+    if world == 1 and not args.no_extras:
+        ctx.set_option("batch_frames", 1)
+        n1 = min(args.steps, 16)
+        ctx.accum_reset(W, H)
+        ctx.render_accumulate(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, n1)     # establishes the tile order
+        ctx.stats_reset()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.render_accumulate(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, n1)
+        wall1 = time.perf_counter() - t0
+        st1 = ctx.stats()
+        single = {"kernel_ms": st1["kernel_ms"] / max(1, st1["frames"]), "wall_ms": wall1 / n1 * 1e3, "frames": n1,
+                  "launches": st1["launches"]}
+        ctx.set_option("batch_frames", min(args.batch, 256))
+
+    # ---- gather ceiling of this GPU on the resident walk array (roofline.gather)
+    gather = None
+    if world == 1 and not args.no_extras and ctx.get_option("traversal") == dr.TRAVERSAL_WIDE:
+        try:
+            gather = {"l2_resident_3MB": ctx.probe_gather(3 * 1024 * 1024 // 64, 4000), "whole_array": ctx.probe_gather(0, 2000),
+                      "array_bytes": 64 * (ctx.get_option("wide_nodes") + ntris)}
+        except Exception as e:
+            log("gather probe failed: %r" % (e,))
 
     # ---- untimed: count what the timed frames traced (same seeds -> same paths)
     ctx.enable_counters(True)
@@ -277,7 +338,8 @@ def main():
     frames_per_launch = timed["frames"] / max(1, timed["launches"])
     abytes = algorithmic_bytes(ref_order, frames, W if world == 1 else W // world, H) / frames
     kbytes = algorithmic_bytes(own, frames, W if world == 1 else W // world, H) / frames
-    achieved = abytes / (kernel_ms * 1e-3) / 1e9
+    algorithmic_gbs = abytes / (kernel_ms * 1e-3) / 1e9
+    records_per_s = own["node_visits"] / frames / (kernel_ms * 1e-3)          # records the kernel's own walk fetched (nodes + leaves)
     result = {
         "metric": "Mrays/sec + ms/frame, 1M-tri .rts at 1920x1080",
         "value": rays / elapsed / 1e6,
@@ -296,8 +358,14 @@ def main():
                         % (ntris, W, H, s.max_depth, args.traversal),
             "triangles": ntris, "width": W, "height": H, "spp_per_frame": 1, "max_depth": int(s.max_depth),
             "frames": frames, "parallelism": "framebuffer block-column stripes x%d" % world,
-            "gather_every": args.gather_every if world > 1 else None, "frames_per_launch": args.batch,
+            "gather_every": args.gather_every if world > 1 else None, "frames_per_launch": frames_per_launch,
+            "mode": "batched: %d frames per launch share one work queue (single_frame_ms: one frame per launch)" % int(round(frames_per_launch)),
         },
+        "repeats": len(region_s),
+        "ms_per_step_min": min(region_s) / frames * 1e3,
+        "ms_per_step_max": max(region_s) / frames * 1e3,
+        "single_frame_ms": single["kernel_ms"] if single else None,
+        "single_frame": single,
         "rays_per_frame": rays / frames,
         "primary_samples_per_s": (W * H * frames) / elapsed,
         "kernel_ms_per_frame": kernel_ms,
@@ -308,34 +376,55 @@ def main():
             "kernel": {"V": own["node_visits"] / own["rays"], "L": own["prim_tests"] / own["rays"],
                        "bytes": kbytes * frames / own["rays"]},
         },
+        # What binds this kernel is VALU issue: one more VALU instruction per node step costs its full 2.4-cycle issue time,
+        # one more 16-byte fetch per lane and step costs 1.4 % (tools/exp_variant.sh).  So the headline is the VALU
+        # roofline on USEFUL work: active-lane VALU operations per second against 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz.
+        # The HBM figures SURVEY 8(d) defines are kept beside it: `hbm` (bytes that reach the fabric, PMC) and `hbm_algorithmic`
+        # (the reference traversal's bytes, mostly served by L1/L2/Infinity Cache -- it may exceed the HBM peak).
         "roofline": {
-            "bound": "hbm",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
+            "bound": "valu",
+            "achieved": None, "peak": VALU_PEAK_LANE_OPS / 1e12, "unit": "Tlaneop/s", "frac": None,
             "traffic": None,
-            "algorithmic_bytes_per_launch": abytes * frames_per_launch,
-            "kernel_own_visit_bytes_per_launch": kbytes * frames_per_launch,
+            "valu": None,
+            "hbm": None,
+            "hbm_algorithmic": {"bytes_per_launch": abytes * frames_per_launch, "GBs": algorithmic_gbs, "frac_of_hbm_peak": algorithmic_gbs / HBM_PEAK_GBS,
+                                "note": "SURVEY 8(d): 32 V + 36 L + 128 S + 4 T + 12 W H with the REFERENCE traversal's visit counts; these bytes are what the "
+                                        "reference algorithm asks for, not what reaches HBM"},
+            "gather": None,
+            "kernel_own_visit_bytes_per_launch": 64 * own["node_visits"] / frames * frames_per_launch,
             "launch_ms": launch_ms,
             "frames_per_launch": frames_per_launch,
-            "note": "algorithmic bytes use the reference traversal's visit counts (SURVEY 8(d)); kernel_own_* uses this kernel's own counts",
         },
-        "setup_s": {"parse": t_parse, "bvh_build": t_bvh, "upload": t_upload},
-        "diag": own.get("diag"),
-        # timed launches: sum of wave lifetimes in shader cycles and in 100 MHz ticks -> clock held, mean wave lifetime
         "timed_waves": {"shader_clock_mhz": 100.0 * timed["diag"][0] / max(1, timed["diag"][7]),
                         "wave_cycles_per_frame": timed["diag"][0] / max(1, timed["frames"])},
+        "setup_s": {"parse": t_parse, "bvh_build": t_bvh, "upload": t_upload},
+        "diag": own.get("diag"),
+
         "simd_efficiency": {"node_loop": ref_order["node_visits"] / max(1, ref_order["trav_slots"]),
                             "bounce_loop": ref_order["rays"] / max(1, ref_order["ray_slots"])},
     }
 
+    rf = result["roofline"]
+    if gather is not None:
+        rf["gather"] = {"records_per_s": records_per_s, "ceiling_l2_resident": gather["l2_resident_3MB"], "ceiling_whole_array_random": gather["whole_array"],
+                        "frac_of_l2_resident_ceiling": records_per_s / gather["l2_resident_3MB"], "record_bytes": 64, "array_bytes": gather["array_bytes"],
+                        "note": "64-byte records fetched by the kernel's own walk per second, against dr_context_probe_gather on the same resident array: "
+                                "divergent dependent fetches within a 3 MB set (L2-resident) and over the whole array (random: below what coherent rays see)"}
     if traffic_probe is not None:
         t = traffic_probe
-        if t is not None:
-            result["roofline"]["traffic"] = t["bytes_per_launch"]
-            result["roofline"]["traffic_note"] = ("rocprofv3 PMC, separate passes, per launch of the timed kernel: 2 x FETCH_SIZE (%.3g B raw; gfx950 reports "
-                                                  "half of 16-B/lane reads) + WRITE_SIZE (%.3g B)" % (t["fetch_size_bytes_raw"], t["write_size_bytes"]))
+        lane_ops = t["SQ_THREAD_CYCLES_VALU"] / (launch_ms * 1e-3)
+        rf["achieved"] = lane_ops / 1e12
+        rf["frac"] = lane_ops / VALU_PEAK_LANE_OPS
+        rf["traffic"] = t["bytes_per_launch"]
+        rf["valu"] = {"wave_instructions_per_launch": t["SQ_INSTS_VALU"], "active_lane_ops_per_launch": t["SQ_THREAD_CYCLES_VALU"],
+                      "lane_use": t["SQ_THREAD_CYCLES_VALU"] / (64.0 * t["SQ_INSTS_VALU"]),
+                      "issue_busy_frac_at_2_cycles_per_instruction": t["SQ_INSTS_VALU"] * 2.0 / (1024 * 2.4e9 * launch_ms * 1e-3),
+                      "wave_instructions_per_ray": t["SQ_INSTS_VALU"] / (rays / frames * frames_per_launch),
+                      "salu_per_launch": t["SQ_INSTS_SALU"], "vmem_rd_per_launch": t["SQ_INSTS_VMEM_RD"]}
+        hbm_gbs = t["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
+        rf["hbm"] = {"achieved_GBs": hbm_gbs, "peak_GBs": HBM_PEAK_GBS, "frac": hbm_gbs / HBM_PEAK_GBS,
+                     "note": "rocprofv3 PMC, separate passes, per launch of the timed kernel: 2 x FETCH_SIZE (%.3g B raw; gfx950 reports half of 16-B/lane reads) "
+                             "+ WRITE_SIZE (%.3g B)" % (t["FETCH_SIZE"], t["WRITE_SIZE"])}
 
     if world == 1 and not args.no_cpu_baseline:
         try:
@@ -363,8 +452,14 @@ def main():
             import numpy as np
             cols = (np.arange(W) // 8) % args.cpu_col_mod == 0
             same = float(np.all(gpu[cols] == img[cols], axis=2).mean())
+            # one thread, every 64th block column of the first frame (about a second of work)
+            t0 = time.perf_counter()
+            _, c1 = osc.render(st, W, H, s.background, seed_base + args.warmup * seed_stride, nthreads=1, col_mod=64, col_rem=0)
+            dt1 = time.perf_counter() - t0
             result["cpu_baseline"] = {
                 "value": cpu_rays / dt / 1e6, "unit": "Mrays/s", "cores": ncpu, "kind": "port",
+                "single_thread": {"value": c1["rays"] / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                                  "sample": "every 64th block column of the first timed frame: %d rays in %.2f s" % (c1["rays"], dt1)},
                 "sample": "oracle (oracle/dogeray_oracle.cpp), %d std::threads (the CPUs this process may use), every %d-th 8-pixel block "
                           "column of the first %d %dx%d frames of the timed region (same scene, same seeds): %d rays in %.2f s "
                           "(+%.1f s oracle parse+BVH, not timed)" % (ncpu, args.cpu_col_mod, nfr, W, H, cpu_rays, dt, t_setup),

@@ -102,9 +102,23 @@ _API = [
     ("dr_accum_read", C.c_int, [_VP, _VP]),
     ("dr_accum_present", C.c_int, [_VP, C.c_int, _VP]),
     ("dr_accum_device_ptr", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
+    ("dr_render_accumulate_async", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_int]),
+    ("dr_context_synchronize", C.c_int, [_VP]),
+    ("dr_context_stream", C.c_int, [_VP, C.POINTER(_VP)]),
+    ("dr_accum_pack_stripe", C.c_int, [_VP, C.c_int, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
+    ("dr_accum_unpack_stripes", C.c_int, [_VP, _VP, C.c_uint64, C.c_int, C.c_int, _VP]),
+    ("dr_group_create", C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
+    ("dr_group_destroy", None, [_VP]),
+    ("dr_group_size", C.c_int, [_VP]),
+    ("dr_group_uses_rccl", C.c_int, [_VP]),
+    ("dr_group_context", _VP, [_VP, C.c_int]),
+    ("dr_group_upload_scene", C.c_int, [_VP, _VP]),
+    ("dr_group_accum_reset", C.c_int, [_VP, C.c_int, C.c_int]),
+    ("dr_group_render_accumulate", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_int, C.c_int]),
     ("dr_stats_enable_counters", C.c_int, [_VP, C.c_int]),
     ("dr_stats_reset", C.c_int, [_VP]),
     ("dr_stats_get", C.c_int, [_VP, C.POINTER(DrStats)]),
+    ("dr_context_probe_gather", C.c_int, [_VP, C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
     ("dr_kat_rng", C.c_int, [_VP, C.c_uint64, C.c_int, _VP]),
     ("dr_kat_aabb", C.c_int, [_VP, C.c_int] + [_VP] * 6),
     ("dr_kat_tri", C.c_int, [_VP, C.c_int] + [_VP] * 6),
@@ -314,6 +328,31 @@ class Context:
         _check(lib().dr_render_accumulate(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1),
                                           int(seed_stride) & (2 ** 64 - 1), nframes))
 
+    def render_accumulate_async(self, settings13, W, H, background, frame_seed, seed_stride, nframes):
+        """Queues the launches and returns (at most two batches in flight); synchronize() waits and updates stats()."""
+        st = _f32(settings13)
+        _check(lib().dr_render_accumulate_async(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1),
+                                                int(seed_stride) & (2 ** 64 - 1), nframes))
+
+    def synchronize(self):
+        _check(lib().dr_context_synchronize(self._h))
+
+    def stream_ptr(self):
+        """The context's hipStream_t as an integer (torch.cuda.ExternalStream(ptr) orders torch work against it)."""
+        p = _VP()
+        _check(lib().dr_context_stream(self._h, C.byref(p)))
+        return p.value or 0
+
+    def accum_pack_stripe(self, slot):
+        """Queues the packing of this context's stripe into library buffer `slot` (0/1); returns (device pointer, bytes)."""
+        p, n = _VP(), C.c_uint64()
+        _check(lib().dr_accum_pack_stripe(self._h, slot, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def accum_unpack_stripes(self, packed_ptr, rank_stride_bytes, world, first_rank=1, stream_ptr=None):
+        _check(lib().dr_accum_unpack_stripes(self._h, C.c_void_p(packed_ptr), int(rank_stride_bytes), world, first_rank,
+                                             C.c_void_p(stream_ptr) if stream_ptr else None))
+
     def accum_read(self):
         out = np.empty(self._acc_shape, dtype=np.int32)
         _check(lib().dr_accum_read(self._h, _p(out)))
@@ -341,6 +380,12 @@ class Context:
         s = DrStats()
         _check(lib().dr_stats_get(self._h, C.byref(s)))
         return s.as_dict()
+
+    def probe_gather(self, hot_records=0, iters=2000):
+        """Records/s of divergent, dependent 64-byte fetches from the resident wide array (bench.py roofline.gather)."""
+        v = C.c_double()
+        _check(lib().dr_context_probe_gather(self._h, int(hot_records), int(iters), C.byref(v)))
+        return v.value
 
     # ---- known-answer hooks (tests)
     def kat_rng(self, seed, n):
@@ -387,6 +432,59 @@ class Context:
         vis = np.zeros(n, dtype=np.int32) if want_visits else None
         _check(lib().dr_kat_hit(self._h, n, _p(o), _p(d), _p(t), _p(idx), _p(vis) if want_visits else None))
         return (t, idx, vis) if want_visits else (t, idx)
+
+
+class Group:
+    """dr_group: one process, one context + one host thread per GPU, stripes gathered to rank 0 (RCCL, or peer copies when
+    ranks share a device).  devices: list of ordinals, e.g. [0, 1, 2, 3] -- or [0, 0, 0] to rehearse on one GPU."""
+
+    def __init__(self, devices):
+        devs = (C.c_int * len(devices))(*devices)
+        h = _VP()
+        _check(lib().dr_group_create(len(devices), devs, C.byref(h)))
+        self._h = h
+        self.size = len(devices)
+
+    def close(self):
+        if self._h:
+            lib().dr_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def uses_rccl(self):
+        return bool(lib().dr_group_uses_rccl(self._h))
+
+    def context(self, rank):
+        """Borrowed Context of one rank (owned by the group: do not close it)."""
+        c = Context.__new__(Context)
+        c._h = _VP(lib().dr_group_context(self._h, rank))
+        c.device = None
+        c.close = lambda: None
+        return c
+
+    def upload(self, scene):
+        _check(lib().dr_group_upload_scene(self._h, scene._h))
+        return self
+
+    def accum_reset(self, W, H):
+        _check(lib().dr_group_accum_reset(self._h, W, H))
+        self._acc_shape = (W, H, 3)
+
+    def render_accumulate(self, settings13, W, H, background, frame_seed, seed_stride, nframes, gather_every=0):
+        st = _f32(settings13)
+        _check(lib().dr_group_render_accumulate(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1),
+                                                int(seed_stride) & (2 ** 64 - 1), nframes, gather_every))
+
+    def accum_read(self):
+        c = self.context(0)
+        c._acc_shape = self._acc_shape
+        return c.accum_read()
 
 
 class ProgressiveRenderer:

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdogeray_amd.so")
-HOST_SOURCES = ["rts_reader.cpp", "bvh_builder.cpp", "linearise.cpp", "wide_builder.cpp", "capi_host.cpp"]
+HOST_SOURCES = ["rts_reader.cpp", "bvh_builder.cpp", "linearise.cpp", "wide_builder.cpp", "capi_host.cpp", "group.cpp"]
 DEVICE_SOURCES = ["context.hip"]
 # -ffp-contract=off: no FMA contraction on host or device -- the BVH build and the kernel's
 # arithmetic are specified operation by operation (DESIGN.md "arithmetic contract").
@@ -45,12 +45,12 @@ def build(force=False, verbose=False):
             slp = [] if os.environ.get("DOGERAY_SLP") == "1" else ["-fno-slp-vectorize"]      # DOGERAY_SLP=1: experiment knob
             cmd = [hipcc] + COMMON + slp + ["--offload-arch=" + ARCH, "-c", sp, "-o", obj]
             if src.endswith(".cpp"):
-                cmd = [hipcc] + COMMON + ["-x", "c++", "-c", sp, "-o", obj]
+                cmd = [hipcc] + COMMON + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-pthread"]
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-pthread", "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // next record is a leaf waits until PARK_MIN lanes have one (the leaf step -- exact box + triangle -- is the long
 // block, as the parked triangle test is in the threaded walk); its stack lives in the first WIDE_STACK words of
 // the wave's LDS region, the phase stash behind it.
-template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE>
+// COOP (wide walk): build with the cooperative drain.  It costs registers (96 instead of 80 and a little scratch), so launches
+// whose queue is long enough to hide their tail use the build without it (launch_persistent picks).
+template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE, bool COOP = true>
 __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, const int* __restrict__ region_start,
                                                                      unsigned* __restrict__ pixel_cost) {
@@ -290,11 +292,11 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
       if (__ballot(tr.node != -3) == 0ull) break;
     }
-    if (!WIDE && !COUNT && P.coop_steps > 0 && cur_tile >= ntiles && (int)__popcll(walking) <= P.coop_lanes) {
+    if (COOP && !COUNT && P.coop_steps > 0 && cur_tile >= ntiles && (int)__popcll(walking) <= P.coop_lanes) {
       // ---- draining (the queue is empty) and only a few lanes of this wave still walk: a ray that is
-      // already old is finished by the whole wave at once (coop_closest_hit) instead of holding the launch
-      // open for hundreds of further dependent steps.  (The counting build keeps the plain walk so that
-      // its counters stay those of the reference order.)
+      // already old is finished by the whole wave at once (coop_closest_hit / coop_closest_hit_wide) instead of holding the
+      // launch open for hundreds of further dependent steps.  (The counting build keeps the plain walk so that
+      // its counters stay those of its traversal order.)
       unsigned long long cand = __ballot(tr.node >= 0 && !(PARK_MIN > 0 && pk.parked) && (int)(steps - rstart) >= P.coop_steps);
       while (cand != 0ull) {
         const int L = __ffsll((long long)cand) - 1;
@@ -304,10 +306,12 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         const V3 ud = mk(bcast(path.raydir.x), bcast(path.raydir.y), bcast(path.raydir.z));
         const V3 ui = mk(bcast(inv.x), bcast(inv.y), bcast(inv.z));
         Hit r;
-        const bool done = coop_closest_hit(P.pairs, P.prims, uo, ud, ui, bcast(tr.best_t), __builtin_amdgcn_readlane(tr.best_slot, L),
-                                           my_lds, r);
+        bool done;
+        if (WIDE) done = coop_closest_hit_wide(walk, P.wide_pmax, uo, ud, ui, bcast(tr.best_t), __builtin_amdgcn_readlane(tr.best_slot, L),
+                                               my_lds + WIDE_STACK * 64, WIDE_STASH * 64, r);       // the phase stash is free between phases
+        else done = coop_closest_hit(P.pairs, P.prims, uo, ud, ui, bcast(tr.best_t), __builtin_amdgcn_readlane(tr.best_slot, L), my_lds, r);
         if (lane == L) {
-          if (done) { tr.best_t = r.t; tr.best_slot = r.slot; tr.node = -1; }
+          if (done) { tr.best_t = r.t; tr.best_slot = r.slot; tr.node = -1; if (WIDE) { ws.top = 0u; ws.sp = 0; } }
           else rstart = 0x80000000u;              // stack overflow: never ask again for this ray ((int)(steps - rstart) is negative from now on)
         }
       }
@@ -477,6 +481,35 @@ __global__ void present_kernel(const int32_t* acc, uint8_t* rgb, int W, int H, i
   }
 }
 
+// Multi-GPU gather (K:1006: the framebuffer is column-major, so an 8-pixel block column is ONE contiguous run of
+// 8*H*3 int32): copies `ncols` such runs between a strided position in a frame and a packed buffer, 16 bytes per lane.
+//   pack    frame column rem + j*mod  ->  packed column j          (dr_accum_pack_stripe)
+//   unpack  packed column j of rank r ->  frame column r + j*R     (dr_accum_unpack_stripes, on rank 0)
+__global__ __launch_bounds__(256) void stripe_copy_kernel(int4* __restrict__ dst, const int4* __restrict__ src, int ncols, int run4,
+                                                          long long dst_first4, long long dst_stride4, long long src_first4, long long src_stride4) {
+  const int col = blockIdx.y;
+  if (col >= ncols) return;
+  int4* d = dst + dst_first4 + (long long)col * dst_stride4;
+  const int4* sp = src + src_first4 + (long long)col * src_stride4;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < run4; i += gridDim.x * blockDim.x) d[i] = sp[i];
+}
+
+// Ceiling probe for the measurement harness (bench.py `roofline.gather`): every lane fetches 64-byte records of the
+// resident wide array at addresses that depend on what it fetched before -- the walk's memory behaviour without its
+// arithmetic.  `nrec` restricts the walk to the first records of the array (a set that fits the L2s, or all of it).
+__global__ __launch_bounds__(256, 5) void gather_probe_kernel(RenderParams P, unsigned nrec, int iters, unsigned* out) {
+  const WalkRsrc r = wide_rsrc(P);
+  unsigned x = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+  unsigned acc = 0;
+  for (int i = 0; i < iters; i++) {
+    const unsigned off = (x % nrec) << 6;
+    const u32x4 a = ld_unit_raw(r, off), b = ld_unit_raw(r, off + 16), c = ld_unit_raw(r, off + 32), d = ld_unit_raw(r, off + 48);
+    acc += a.x ^ b.y ^ c.z ^ d.w;
+    x = x * 1664525u + 1013904223u + (acc & 1u);
+  }
+  if (acc == 0x12345678u) out[0] = acc;
+}
+
 // ---- known-answer kernels
 __global__ void kat_rng_kernel(uint64_t seed, int n, double* out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -542,6 +575,9 @@ struct dr_context {
   int device = 0;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // dr_render_accumulate_async: two batches may be in flight, each with its own pair of events
+  hipEvent_t pev0[2] = {nullptr, nullptr}, pev1[2] = {nullptr, nullptr};
+  bool pending[2] = {false, false}; uint64_t pending_frames[2] = {0, 0}, pending_samples[2] = {0, 0}; int pending_next = 0;
   // resident scene
   DevUnit* walk = nullptr; size_t walk_bytes = 0;
   DevUnit* wide = nullptr; size_t wide_bytes = 0; int wide_depth = 0, wide_nodes = 0; float wide_pmax = 0;   // null: scene not representable (threaded walk is used)
@@ -557,6 +593,8 @@ struct dr_context {
   int32_t* frame = nullptr; size_t frame_elems = 0;
   int32_t* accum = nullptr; size_t accum_elems = 0; int accW = 0, accH = 0;
   uint8_t* present = nullptr; size_t present_bytes = 0;
+  // multi-GPU gather: two packed copies of this context's stripe (double buffer), sized for the accumulator
+  int32_t* packed[2] = {nullptr, nullptr}; size_t packed_elems[2] = {0, 0};
   unsigned long long* counters = nullptr;
   unsigned* tile_counters = nullptr; int tile_cursor = 0; int num_cus = 256;
   // cost feedback (persistent kernel): per-pixel cost of the last frame, per-tile cost, tile order
@@ -576,7 +614,8 @@ struct dr_context {
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
   int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural, -1 = all by cost)
-  int coop_steps = 64;      // persistent kernel, drain phase: rays older than this are finished cooperatively (0 = off)
+  int coop_steps = 16;      // persistent kernel, drain phase: rays older than this many steps are finished cooperatively (0 = off)
+  int coop_tiles_per_wave = 64;   // wide walk: launches with fewer tiles per wave than this run the build with the cooperative drain
   int coop_lanes = 8;       // ... in waves with at most this many lanes still walking
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
   float cur_settings[13] = {0};
@@ -713,8 +752,11 @@ void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, 
   if (blocks * 4 > work) blocks = (work + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
   if (traversal_of(c) == DR_TRAVERSAL_WIDE) {
-    if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
-    else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
+    // the cooperative drain shortens a launch's tail; with many tiles per wave the tail does not show and the leaner build is faster
+    const bool coop = P.coop_steps > 0 && (long long)work < (long long)c->coop_tiles_per_wave * blocks * 4;
+    if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, false>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
+    else if (coop) hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, true>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
+    else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, false>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
     return;
   }
   if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, false>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
@@ -794,6 +836,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "heavy_factor") { if (v < -1 || v > 1000) goto bad; c->heavy_factor = v; c->order_valid = false; }
   else if (name == "coop_steps") { if (v < 0) goto bad; c->coop_steps = v; }
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
+  else if (name == "coop_tiles_per_wave") { if (v < 0) goto bad; c->coop_tiles_per_wave = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
@@ -876,7 +919,8 @@ int dr_context_create(int device_ordinal, dr_context** out) {
   memset(&c->stats, 0, sizeof(c->stats));
   // the stream first: every memset below is ordered on it, like the kernels that use the buffers
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&c->ev0) != hipSuccess ||
-      hipEventCreate(&c->ev1) != hipSuccess) {
+      hipEventCreate(&c->ev1) != hipSuccess || hipEventCreate(&c->pev0[0]) != hipSuccess || hipEventCreate(&c->pev1[0]) != hipSuccess ||
+      hipEventCreate(&c->pev0[1]) != hipSuccess || hipEventCreate(&c->pev1[1]) != hipSuccess) {
     set_error("cannot create stream/events");
     dr_context_destroy(c);
     return DR_ERR_DEVICE;
@@ -898,10 +942,11 @@ void dr_context_destroy(dr_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* bufs[] = {c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
+  void* bufs[] = {c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
+  for (int k = 0; k < 2; k++) { if (c->pev0[k]) (void)hipEventDestroy(c->pev0[k]); if (c->pev1[k]) (void)hipEventDestroy(c->pev1[k]); }
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -965,6 +1010,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "heavy_factor") *value = c->heavy_factor;
   else if (n == "coop_steps") *value = c->coop_steps;
   else if (n == "coop_lanes") *value = c->coop_lanes;
+  else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
   else if (n == "tree_depth") *value = c->tree_depth;
   else if (n == "wide_tree") *value = c->wide_tree;
   else if (n == "wide_depth") *value = c->wide ? c->wide_depth : 0;          // 0: the scene has no wide structure
@@ -1020,12 +1066,16 @@ int dr_accum_reset(dr_context* c, int W, int H) {
   return DR_OK;
 }
 
-int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
-                         uint64_t seed_stride, int nframes) {
+}  // extern "C"
+
+namespace {
+// enqueues the launches of `nframes` frames between two event records; no host synchronisation
+int accumulate_enqueue(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
+                       uint64_t seed_stride, int nframes, hipEvent_t e0, hipEvent_t e1, uint64_t& samples) {
+  samples = 0;
   if (!c || !settings13 || nframes < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
   if (!c->accum || c->accW != W || c->accH != H) { set_error("call dr_accum_reset(W, H) first"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
-  if (nframes == 0) return DR_OK;
   RenderParams P;
   int rc = make_params(c, settings13, W, H, background, frame_seed, P);
   if (rc != DR_OK) return rc;
@@ -1033,13 +1083,12 @@ int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H
   P.out = c->accum;
   P.accumulate = 1;
   int tiles = P.ncols * P.gy;
-  if (tiles <= 0) return DR_OK;
-  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(hipEventRecord(e0, c->stream));
   // The persistent kernel renders the frames in batches of `batch_frames` per launch (one work
   // queue over all their tiles, atomic accumulation); the per-tile kernel takes one frame per launch.
   const int per_launch = (uses_persistent(c) && c->batch_frames > 1) ? c->batch_frames : 1;
   uint64_t launches = 0;
-  for (int k = 0; k < nframes; k += per_launch) {
+  for (int k = 0; k < nframes && tiles > 0; k += per_launch) {
     P.seed = frame_seed + (uint64_t)k * seed_stride;
     P.batch = nframes - k < per_launch ? nframes - k : per_launch;
     P.batch_seed_stride = seed_stride;
@@ -1049,10 +1098,109 @@ int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H
   }
   c->stats.launches += launches;
   HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(c->ev1, c->stream));
-  uint64_t samples = (uint64_t)tiles * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0) * (uint64_t)nframes;
+  HIP_TRY(hipEventRecord(e1, c->stream));
+  samples = (uint64_t)(tiles > 0 ? tiles : 0) * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0) * (uint64_t)nframes;
+  return DR_OK;
+}
+
+// time of an asynchronous batch whose events are still outstanding (waits for that batch, not for later ones)
+int collect_pending(dr_context* c, int k) {
+  if (!c->pending[k]) return DR_OK;
+  HIP_TRY(hipEventSynchronize(c->pev1[k]));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, c->pev0[k], c->pev1[k]));
+  c->stats.kernel_ms += ms;
+  c->stats.frames += c->pending_frames[k];
+  c->stats.samples += c->pending_samples[k];
+  c->pending[k] = false;
+  return DR_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
+                         uint64_t seed_stride, int nframes) {
+  if (!c) { set_error("bad argument"); return DR_ERR_INVALID; }
+  if (nframes == 0) return DR_OK;
+  uint64_t samples = 0;
+  int rc = accumulate_enqueue(c, settings13, W, H, background, frame_seed, seed_stride, nframes, c->ev0, c->ev1, samples);
+  if (rc != DR_OK) return rc;
   if ((rc = collect_time(c, (uint64_t)nframes, samples)) != DR_OK) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
+  return DR_OK;
+}
+
+int dr_render_accumulate_async(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
+                               uint64_t seed_stride, int nframes) {
+  if (!c) { set_error("bad argument"); return DR_ERR_INVALID; }
+  if (nframes == 0) return DR_OK;
+  const int k = c->pending_next;
+  int rc = collect_pending(c, k);           // at most two batches in flight: reusing a pair of events waits for the batch before last
+  if (rc != DR_OK) return rc;
+  uint64_t samples = 0;
+  if ((rc = accumulate_enqueue(c, settings13, W, H, background, frame_seed, seed_stride, nframes, c->pev0[k], c->pev1[k], samples)) != DR_OK) return rc;
+  c->pending[k] = true; c->pending_frames[k] = (uint64_t)nframes; c->pending_samples[k] = samples;
+  c->pending_next = k ^ 1;
+  return DR_OK;
+}
+
+int dr_context_synchronize(dr_context* c) {
+  if (!c) { set_error("null context"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  int rc;
+  if ((rc = collect_pending(c, c->pending_next)) != DR_OK) return rc;       // older first
+  if ((rc = collect_pending(c, c->pending_next ^ 1)) != DR_OK) return rc;
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return DR_OK;
+}
+
+int dr_context_stream(dr_context* c, void** hip_stream) {
+  if (!c || !hip_stream) { set_error("null argument"); return DR_ERR_INVALID; }
+  *hip_stream = (void*)c->stream;
+  return DR_OK;
+}
+
+int dr_accum_pack_stripe(dr_context* c, int slot, void** dev_ptr, uint64_t* bytes) {
+  if (!c || !c->accum || (slot != 0 && slot != 1)) { set_error("pack: no accumulator, or slot not 0/1"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  const int gx = c->accW / 8;
+  const int ncols = gx > c->stripe_rem ? (gx - c->stripe_rem + c->stripe_mod - 1) / c->stripe_mod : 0;
+  const size_t run = (size_t)8 * (size_t)c->accH * 3;                 // int32 per block column
+  // sized for the largest stripe of this partition (rank 0's), so that every rank's buffer can take part in one
+  // equal-sized gather
+  const size_t need = (size_t)((gx + c->stripe_mod - 1) / c->stripe_mod > 0 ? (gx + c->stripe_mod - 1) / c->stripe_mod : 1) * run;
+  int rc = ensure(c->packed[slot], c->packed_elems[slot], need);
+  if (rc != DR_OK) return rc;
+  if (ncols > 0) {
+    const int run4 = (int)(run / 4);
+    int bx = (run4 + 255) / 256; if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(stripe_copy_kernel, dim3((unsigned)bx, (unsigned)ncols), dim3(256), 0, c->stream, reinterpret_cast<int4*>(c->packed[slot]),
+                       reinterpret_cast<const int4*>(c->accum), ncols, run4, 0ll, (long long)run4, (long long)c->stripe_rem * run4, (long long)c->stripe_mod * run4);
+    HIP_TRY(hipGetLastError());
+  }
+  if (dev_ptr) *dev_ptr = c->packed[slot];
+  if (bytes) *bytes = (uint64_t)ncols * run * sizeof(int32_t);
+  return DR_OK;
+}
+
+int dr_accum_unpack_stripes(dr_context* c, const void* packed_dev, uint64_t rank_stride_bytes, int world, int first_rank, void* hip_stream) {
+  if (!c || !c->accum || !packed_dev || world < 1 || first_rank < 0 || first_rank > world || (rank_stride_bytes & 15ull)) { set_error("unpack: bad argument"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  hipStream_t stream = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  const int gx = c->accW / 8;
+  const size_t run = (size_t)8 * (size_t)c->accH * 3;
+  const int run4 = (int)(run / 4);
+  int bx = (run4 + 255) / 256; if (bx > 64) bx = 64;
+  for (int r = first_rank; r < world; r++) {
+    const int ncols = gx > r ? (gx - r + world - 1) / world : 0;
+    if (ncols == 0) continue;
+    if ((uint64_t)ncols * run * sizeof(int32_t) > rank_stride_bytes) { set_error("unpack: a rank's stripe is larger than rank_stride_bytes"); return DR_ERR_INVALID; }
+    hipLaunchKernelGGL(stripe_copy_kernel, dim3((unsigned)bx, (unsigned)ncols), dim3(256), 0, stream, reinterpret_cast<int4*>(c->accum),
+                       reinterpret_cast<const int4*>(packed_dev), ncols, run4, (long long)r * run4, (long long)world * run4,
+                       (long long)((uint64_t)r * rank_stride_bytes / 16), (long long)run4);
+  }
+  HIP_TRY(hipGetLastError());
   return DR_OK;
 }
 
@@ -1115,6 +1263,31 @@ int dr_stats_get(dr_context* c, dr_stats* out) {
   if (c->count) out->samples = h[5];
   out->trav_slots = h[6]; out->ray_slots = h[7];
   for (int k = 0; k < 8; k++) out->diag[k] = h[8 + k];
+  return DR_OK;
+}
+
+int dr_context_probe_gather(dr_context* c, uint32_t hot_records, int iters, double* records_per_s) {
+  if (!c || !records_per_s || iters < 1) { set_error("bad argument"); return DR_ERR_INVALID; }
+  if (!c->wide) { set_error("no wide walk resident"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  RenderParams P;
+  memset(&P, 0, sizeof(P));
+  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes;
+  const unsigned total = (unsigned)(c->wide_bytes / 64);
+  const unsigned nrec = (hot_records == 0 || hot_records > total) ? total : hot_records;
+  DevBuf<unsigned> out;
+  int rc = out.alloc(1);
+  if (rc != DR_OK) return rc;
+  const int blocks = c->num_cus * 5;
+  hipLaunchKernelGGL(gather_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, P, nrec, iters / 8 + 1, out.p);      // warm-up
+  HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  hipLaunchKernelGGL(gather_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, c->stream, P, nrec, iters, out.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  HIP_TRY(hipEventSynchronize(c->ev1));
+  float ms = 0;
+  HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+  *records_per_s = (double)blocks * 256.0 * (double)iters / ((double)ms * 1e-3);
   return DR_OK;
 }
 

@@ -292,7 +292,7 @@ __device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk
 // (equal t goes to the lower slot = the leaf the reference's walk reaches first).  Used only while a
 // launch drains (persistent kernel): idle lanes shorten the few long rays that set the launch time.
 constexpr int WAVE_LDS_DWORDS = 24 * 64;  // per-wave LDS region of the persistent kernel (6 KiB): phase stash / cooperative stack
-constexpr int WIDE_STASH = 16;             // phase stash of the WIDE persistent kernel, dwords per lane (behind the WIDE_STACK stack words)
+constexpr int WIDE_STASH = 15;             // phase stash of the WIDE persistent kernel, dwords per lane (behind the WIDE_STACK stack words)
 constexpr int COOP_STACK = WAVE_LDS_DWORDS;   // node stack entries; a deeper frontier falls back to the plain walk
 
 __device__ __forceinline__ float wave_min_f32(float v) {
@@ -532,6 +532,83 @@ template <bool COUNT>
 __device__ __forceinline__ void wide_node_step(WalkRsrc wide, V3 o, V3 inv, const WideRay& wr, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
   const WideRec r = wide_fetch(wide, tr.node);
   wide_node_compute<COUNT>(r, o, inv, wr, tr, ws, stack, c);
+}
+
+// Cooperative closest hit over the wide walk: all 64 lanes of a wave answer ONE query (the wide-walk counterpart of
+// coop_closest_hit above, used by the persistent kernel while a launch drains: a ray that would cost one lane hundreds
+// of dependent steps is finished in a few dozen rounds).  The wave keeps a stack of record references (index << 1 |
+// is-leaf) in LDS; per round every lane pops one, fetches its record, and either tests the leaf (exact box, primitive)
+// or tests the node's four children against the wave's best t and pushes those that pass.  The result is the
+// lexicographic minimum (t, slot) over every leaf whose own box the ray enters no farther than the best t -- the
+// reference's hit by the same argument as the per-lane walk; the visiting order does not enter it.
+// Returns false (no result) if the stack would overflow; the caller then keeps walking the plain way.
+__device__ __forceinline__ bool coop_closest_hit_wide(WalkRsrc wide, float pmax, V3 o, V3 d, V3 inv, float bound_t, int bound_slot,
+                                                      int* __restrict__ stack, int capacity, Hit& out) {
+  const int lane = (int)__lane_id();
+  const WideRay wr = wide_ray(o, inv, pmax);
+  float best_t = bound_t;
+  unsigned best_slot = (unsigned)bound_slot;            // -1 = none: the largest unsigned
+  float prune_t = bound_t;
+  int n = 1;
+  if (lane == 0) stack[0] = 0;                          // the root node
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  bool ok = true;
+  while (n > 0) {
+    const int take = n < 64 ? n : 64;
+    int ref = -1;
+    if (lane < take) ref = stack[n - 1 - lane];
+    n -= take;
+    unsigned push = 0u, base = 0u, leafmask = 0u;
+    if (ref >= 0) {
+      const WideRec r = wide_fetch(wide, ref);
+      if (ref & 1) {
+        auto f = [](unsigned v) { return __uint_as_float(v); };
+        float mn[3] = {f(r.A.x), f(r.A.y), f(r.A.z)}, mx[3] = {f(r.B.x), f(r.B.y), f(r.B.z)};
+        float dist;
+        if (slab(o, inv, mn, mx, dist) && dist <= prune_t) {
+          const int info = (int)r.A.w;
+          const float t = prim_hit_kind((info >> WALK_SLOT_BITS) & 3, mk(f(r.B.w), f(r.C.x), f(r.C.y)), mk(f(r.C.z), f(r.C.w), f(r.D.x)), mk(f(r.D.y), f(r.D.z), f(r.D.w)), o, d);
+          const unsigned slot = (unsigned)(info & ((1 << WALK_SLOT_BITS) - 1));
+          if (t > 0.0f && (t < best_t || (t == best_t && slot < best_slot))) { best_t = t; best_slot = slot; }
+        }
+      } else {
+        unsigned key;
+        push = wide_node_test(r.A, r.B, r.C, r.D, o, DR_WIDE_FOLD ? wr.inv : inv, wr.marg, prune_t, key);
+        base = r.A.w & 0xffffffu; leafmask = (r.B.w >> 4) & 15u;
+      }
+    }
+    // every lane pushes the children it entered: positions from four ballots
+    int total = 0, pos[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const unsigned long long m = __ballot((push >> k) & 1u);
+      pos[k] = n + total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+      total += __popcll(m);
+    }
+    if (n + total > capacity) { ok = false; break; }
+    __builtin_amdgcn_wave_barrier();            // every lane has read its entry before anyone overwrites it
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if ((push >> k) & 1u) stack[pos[k]] = (int)(((base + (unsigned)k) << 1) | ((leafmask >> k) & 1u));
+    n += total;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    prune_t = wave_min_f32(best_t);
+  }
+  if (!ok) return false;
+  for (int off = 32; off > 0; off >>= 1) {      // lexicographic minimum (t, slot) over the lanes
+    const float ot = __shfl_xor(best_t, off, 64);
+    const unsigned os = (unsigned)__shfl_xor((int)best_slot, off, 64);
+    const bool take_other = ot < best_t || (ot == best_t && os < best_slot);
+    best_t = take_other ? ot : best_t;
+    best_slot = take_other ? os : best_slot;
+  }
+  out.t = best_t;
+  out.slot = (int)best_slot;
+  return true;
 }
 
 template <bool COUNT>

@@ -77,11 +77,14 @@ bool write_bmp(const std::string& path, const std::vector<uint8_t>& rgb, int W, 
 void usage() {
   fprintf(stderr,
           "usage: dogeray [scene.rts] [--textures DIR] [--frames N] [--out FILE.bmp|.ppm] [--width W] [--height H]\n"
-          "               [--spp S] [--depth D] [--seed N] [--device I] [--group G] [--cache] [--quiet]\n"
+          "               [--spp S] [--depth D] [--seed N] [--device I] [--gpus N] [--group G] [--gather-every K] [--cache] [--quiet]\n"
           "  scene        .rts file (default scene.rts, as the reference)\n"
           "  --textures   directory scanned for *ppm* textures (default: current directory, as the reference)\n"
           "  --frames     full-resolution frames to accumulate after the 4 preview stages (default 64)\n"
           "  --group      frames rendered between two presents once accumulating (default 8)\n"
+          "  --gpus       N > 1: GPUs 0..N-1 of this node render interleaved 8-pixel block columns of every frame (one context and one\n"
+          "               host thread each); the stripes are gathered to GPU 0 over RCCL every --gather-every frames (default: once per\n"
+          "               present), the gather of one batch running beside the rendering of the next\n"
           "  --cache      keep a binary image of the parsed scene + BVH next to the scene (scene.rtsb) and start from\n"
           "               it while it is newer than the .rts ('r' fields and textures are frozen in it: delete it to redraw)\n");
 }
@@ -91,7 +94,7 @@ void usage() {
 int main(int argc, char** argv) {
   std::string scene_path = "scene.rts", out_path;
   const char* texdir = nullptr;
-  int frames = 64, device = 0, group = 8, width = 0, height = 0, spp = 0, depth = 0;
+  int frames = 64, device = 0, group = 8, width = 0, height = 0, spp = 0, depth = 0, gpus = 1, gather_every = 0;
   uint64_t seed = 1;
   bool quiet = false, have_scene = false, use_cache = false;
   for (int i = 1; i < argc; i++) {
@@ -107,6 +110,8 @@ int main(int argc, char** argv) {
     else if (a == "--seed") seed = strtoull(next(), nullptr, 10);
     else if (a == "--device") device = atoi(next());
     else if (a == "--group") group = atoi(next());
+    else if (a == "--gpus") gpus = atoi(next());
+    else if (a == "--gather-every") gather_every = atoi(next());
     else if (a == "--quiet") quiet = true;
     else if (a == "--cache") use_cache = true;
     else if (a == "-h" || a == "--help") { usage(); return 0; }
@@ -143,11 +148,26 @@ int main(int argc, char** argv) {
   double bvh_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   printf("Done!\n%d nodes total (%.0f ms)\n", dr_scene_bvh_size(scene), bvh_ms);               // K:2093-2094
 
+  // one GPU: a context; several: a group (rank 0 = GPU 0 assembles and presents)
   dr_context* ctx = nullptr;
-  if (dr_context_create(device, &ctx) != DR_OK) die("cannot create the device context");
-  if (dr_context_upload_scene(ctx, scene) != DR_OK) die("cannot upload the scene");
+  dr_group* grp = nullptr;
   const int W = s.width, H = s.height;
-  if (dr_accum_reset(ctx, W, H) != DR_OK) die("cannot allocate the accumulator");
+  if (gpus > 1) {
+    if (dr_group_create(gpus, nullptr, &grp) != DR_OK) die("cannot create the GPU group");
+    if (dr_group_upload_scene(grp, scene) != DR_OK) die("cannot upload the scene");
+    if (dr_group_accum_reset(grp, W, H) != DR_OK) die("cannot allocate the accumulators");
+    ctx = dr_group_context(grp, 0);
+    if (!quiet) printf("%d GPUs, stripes gathered to GPU 0 by %s\n", gpus, dr_group_uses_rccl(grp) ? "RCCL send/recv" : "peer copies");
+  } else {
+    if (dr_context_create(device, &ctx) != DR_OK) die("cannot create the device context");
+    if (dr_context_upload_scene(ctx, scene) != DR_OK) die("cannot upload the scene");
+    if (dr_accum_reset(ctx, W, H) != DR_OK) die("cannot allocate the accumulator");
+  }
+  auto reset = [&]() { return grp ? dr_group_accum_reset(grp, W, H) : dr_accum_reset(ctx, W, H); };
+  auto render = [&](const float* st13, uint64_t sd, int n) {
+    return grp ? dr_group_render_accumulate(grp, st13, W, H, s.background, sd, 1000003, n, gather_every)
+               : dr_render_accumulate(ctx, st13, W, H, s.background, sd, 1000003, n);
+  };
 
   // ---- the present loop (K:2154-2224)
   int iter = 0;
@@ -164,14 +184,14 @@ int main(int argc, char** argv) {
       static const int ladder[4] = {8, 4, 2, 1};
       // iter 0 runs with the file's spp/depth, iters 1-3 with spp 1 / depth 2 (K:2171-2204)
       pack13(s, ladder[iter], iter == 0 ? s.spp : 1, iter == 0 ? s.max_depth : 2, st);
-      if (dr_accum_reset(ctx, W, H) != DR_OK) die("reset");          // CudaStarter overwrites outr on these calls
+      if (reset() != DR_OK) die("reset");                            // CudaStarter overwrites outr on these calls
       pnum = iter;
     } else {
       pack13(s, 1, s.spp, s.max_depth, st);
       n = total_iters - iter < group ? total_iters - iter : group;   // several frames per present
       pnum = 3;
     }
-    if (dr_render_accumulate(ctx, st, W, H, s.background, seed + frame_no * seed_stride, seed_stride, n) != DR_OK) die("render");
+    if (render(st, seed + frame_no * seed_stride, n) != DR_OK) die("render");
     frame_no += (uint64_t)n;
     iter += n;
     divide_by = iter - pnum;                                          // K:2287
@@ -193,7 +213,7 @@ int main(int argc, char** argv) {
     if (!ok) { fprintf(stderr, "dogeray: cannot write %s\n", out_path.c_str()); return 1; }
     printf("exported image:%s\n", out_path.c_str());                  // K:2515
   }
-  dr_context_destroy(ctx);
+  if (grp) dr_group_destroy(grp); else dr_context_destroy(ctx);
   dr_scene_free(scene);
   return 0;
 }

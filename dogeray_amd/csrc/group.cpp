@@ -1,0 +1,293 @@
+// dr_group: one process, one device context and one host thread per GPU, framebuffer stripes gathered to rank 0.
+//
+// The reference is single-device (kernel.cu K:2614-2615).  Pixels are independent and seeded by (x, y, frame) (K:1065),
+// so rank r of R renders the 8-pixel block columns bx % R == r (dr_context_set_stripe) of every frame into its own
+// accumulator; every `gather_every` frames each rank packs its stripe (one contiguous run of 8*H*3 int32 per column,
+// K:1006) and sends it to rank 0, which writes it into its accumulator's columns r, r+R, ....  Everything is queued:
+//
+//   render stream (per rank)   [render batch k] [pack -> slot k&1] ........ [render batch k+1] [pack -> slot (k+1)&1]
+//   comm stream   (per rank)                     wait packed(k) : ncclSend / ncclRecv x (R-1) + unpack : record sent(k)
+//
+// so the gather of batch k runs beside the rendering of batch k+1 (ranks render disjoint columns, the unpack on rank 0
+// touches only other ranks' columns); a slot is packed again only after its send has finished (render stream waits on
+// sent(k-2)).  Transport: RCCL point-to-point (ncclSend / ncclRecv, grouped on rank 0: the R-1 transfers land on R-1
+// distinct xGMI links), resolved from librccl.so at run time; DOGERAY_GROUP_TRANSPORT=copy (or several ranks on one
+// device, as the single-GPU tests do) uses hipMemcpyPeerAsync + events instead.
+// This file is a client of the C ABI (include/dogeray_amd.h) plus HIP events/streams and RCCL: no kernels.
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <condition_variable>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "scene_host.hpp"
+
+using namespace dr;
+
+namespace {
+
+struct Rccl {
+  void* handle = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load() {
+    if (handle) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (handle) break;
+    }
+    if (!handle) return false;
+    auto sym = [&](const char* n) { return dlsym(handle, n); };
+    CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
+    CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+    GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+    Send = (decltype(Send))sym("ncclSend");
+    Recv = (decltype(Recv))sym("ncclRecv");
+    GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+    return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+  }
+};
+
+// all ranks meet here once per batch (copy transport only: an event must have been recorded before another thread waits on it)
+struct Rendezvous {
+  std::mutex m; std::condition_variable cv; int waiting = 0; unsigned long generation = 0; int n = 1; bool aborted = false;
+  void arrive() {
+    std::unique_lock<std::mutex> lk(m);
+    const unsigned long g = generation;
+    if (++waiting == n) { waiting = 0; generation++; cv.notify_all(); }
+    else cv.wait(lk, [&] { return generation != g || aborted; });
+  }
+  void abort() { std::lock_guard<std::mutex> lk(m); aborted = true; cv.notify_all(); }      // a rank failed: nobody waits for it
+};
+
+}  // namespace
+
+struct dr_group {
+  int n = 0;
+  std::vector<int> device;
+  std::vector<dr_context*> ctx;
+  std::vector<hipStream_t> comm;                   // one communication stream per rank, on that rank's device
+  std::vector<hipEvent_t> packed[2], sent[2];      // per slot, per rank
+  bool use_rccl = false;
+  Rccl rccl;
+  std::vector<ncclComm_t> comms;
+  int32_t* stage[2] = {nullptr, nullptr};          // rank 0's device: [n][stage_stride] int32 per slot
+  size_t stage_stride = 0;                         // int32 per rank
+  int W = 0, H = 0;
+  Rendezvous meet;
+  std::string error;                               // first failure of a worker
+  std::mutex error_lock;
+  void fail(const std::string& msg) { { std::lock_guard<std::mutex> g(error_lock); if (error.empty()) error = msg; } meet.abort(); }
+};
+
+namespace {
+
+#define G_HIP(expr)                                                                                       \
+  do {                                                                                                    \
+    hipError_t e_ = (expr);                                                                               \
+    if (e_ != hipSuccess) { g->fail(std::string(#expr) + ": " + hipGetErrorString(e_)); return false; }   \
+  } while (0)
+#define G_NCCL(expr)                                                                                      \
+  do {                                                                                                    \
+    ncclResult_t r_ = (expr);                                                                             \
+    if (r_ != ncclSuccess) { g->fail(std::string(#expr) + ": " + g->rccl.GetErrorString(r_)); return false; } \
+  } while (0)
+#define G_DR(expr)                                                                                        \
+  do {                                                                                                    \
+    if ((expr) != DR_OK) { g->fail(std::string(#expr) + ": " + dr_last_error()); return false; }          \
+  } while (0)
+
+size_t stripe_elems(int W, int H, int world, int rank) {
+  const int gx = W / 8;
+  const int ncols = gx > rank ? (gx - rank + world - 1) / world : 0;
+  return (size_t)ncols * 8 * (size_t)H * 3;
+}
+
+// one rank's share of dr_group_render_accumulate
+bool rank_work(dr_group* g, int r, const float* st, int W, int H, float bg, uint64_t seed, uint64_t stride, int nframes, int every) {
+  G_HIP(hipSetDevice(g->device[(size_t)r]));
+  dr_context* c = g->ctx[(size_t)r];
+  hipStream_t render = nullptr;
+  G_DR(dr_context_stream(c, (void**)&render));
+  hipStream_t comm = g->comm[(size_t)r];
+  const bool copy = !g->use_rccl;
+  int batch = 0;
+  for (int k = 0; k < nframes; k += every, batch++) {
+    const int n = nframes - k < every ? nframes - k : every;
+    const int slot = batch & 1;
+    if (batch >= 2) G_HIP(hipStreamWaitEvent(render, g->sent[slot][(size_t)r], 0));     // the slot's previous contents have left
+    G_DR(dr_render_accumulate_async(c, st, W, H, bg, seed + (uint64_t)k * stride, stride, n));
+    if (g->n == 1) continue;
+    void* pk = nullptr; uint64_t bytes = 0;
+    if (r != 0) G_DR(dr_accum_pack_stripe(c, slot, &pk, &bytes));            // rank 0's own columns are already where they belong
+    G_HIP(hipEventRecord(g->packed[slot][(size_t)r], render));
+    G_HIP(hipStreamWaitEvent(comm, g->packed[slot][(size_t)r], 0));
+    int32_t* stage = g->stage[slot];
+    if (copy) {
+      if (r != 0 && bytes) G_HIP(hipMemcpyPeerAsync(stage + (size_t)r * g->stage_stride, g->device[0], pk, g->device[(size_t)r], bytes, comm));
+      G_HIP(hipEventRecord(g->sent[slot][(size_t)r], comm));
+      g->meet.arrive();                                        // every rank has recorded sent(batch)
+      if (r == 0) {
+        for (int q = 1; q < g->n; q++) G_HIP(hipStreamWaitEvent(comm, g->sent[slot][(size_t)q], 0));
+        G_DR(dr_accum_unpack_stripes(c, stage, g->stage_stride * sizeof(int32_t), g->n, 1, comm));
+        G_HIP(hipEventRecord(g->sent[slot][0], comm));
+      }
+      g->meet.arrive();                                        // nobody re-records an event rank 0 has not yet waited on
+    } else {
+      if (r != 0) {
+        if (bytes) G_NCCL(g->rccl.Send(pk, bytes / sizeof(int32_t), ncclInt32, 0, g->comms[(size_t)r], comm));
+      } else {
+        G_NCCL(g->rccl.GroupStart());
+        for (int q = 1; q < g->n; q++) {
+          const size_t cnt = stripe_elems(W, H, g->n, q);
+          if (cnt) G_NCCL(g->rccl.Recv(stage + (size_t)q * g->stage_stride, cnt, ncclInt32, q, g->comms[0], comm));
+        }
+        G_NCCL(g->rccl.GroupEnd());
+        G_DR(dr_accum_unpack_stripes(c, stage, g->stage_stride * sizeof(int32_t), g->n, 1, comm));
+      }
+      G_HIP(hipEventRecord(g->sent[slot][(size_t)r], comm));
+    }
+  }
+  G_HIP(hipStreamSynchronize(comm));
+  G_DR(dr_context_synchronize(c));
+  return true;
+}
+
+bool for_all_ranks(dr_group* g, const std::function<bool(int)>& f) {
+  std::vector<std::thread> th;
+  std::vector<char> ok((size_t)g->n, 0);
+  for (int r = 0; r < g->n; r++) th.emplace_back([&, r] { ok[(size_t)r] = f(r) ? 1 : 0; });
+  for (std::thread& t : th) t.join();
+  for (char o : ok) if (!o) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dr_group_create(int n, const int* device_ordinals, dr_group** out) {
+  if (!out || n < 1) { set_error("group: need n >= 1"); return DR_ERR_INVALID; }
+  *out = nullptr;
+  dr_group* g = new dr_group();
+  g->n = n;
+  g->meet.n = n;
+  bool distinct = true;
+  // DOGERAY_GROUP_DEVICES="0,0,0": ordinals for a caller that passes none (rehearsing `dogeray --gpus 3` on one GPU)
+  std::vector<int> env_dev;
+  if (const char* e = getenv("DOGERAY_GROUP_DEVICES")) {
+    for (const char* p = e; *p;) { env_dev.push_back(atoi(p)); while (*p && *p != ',') p++; if (*p == ',') p++; }
+  }
+  for (int r = 0; r < n; r++) {
+    g->device.push_back(device_ordinals ? device_ordinals[r] : (r < (int)env_dev.size() ? env_dev[(size_t)r] : r));
+    for (int q = 0; q < r; q++) if (g->device[(size_t)q] == g->device[(size_t)r]) distinct = false;
+  }
+  const char* tr = getenv("DOGERAY_GROUP_TRANSPORT");
+  g->use_rccl = n > 1 && distinct && !(tr && std::string(tr) == "copy");
+  auto bail = [&](int rc, const std::string& msg) { set_error(msg); dr_group_destroy(g); return rc; };
+  g->ctx.assign((size_t)n, nullptr);
+  g->comm.assign((size_t)n, nullptr);
+  for (int k = 0; k < 2; k++) { g->packed[k].assign((size_t)n, nullptr); g->sent[k].assign((size_t)n, nullptr); }
+  for (int r = 0; r < n; r++) {
+    if (dr_context_create(g->device[(size_t)r], &g->ctx[(size_t)r]) != DR_OK) return bail(DR_ERR_DEVICE, std::string("group: ") + dr_last_error());
+    if (dr_context_set_stripe(g->ctx[(size_t)r], n, r) != DR_OK) return bail(DR_ERR_INVALID, std::string("group: ") + dr_last_error());
+    if (hipSetDevice(g->device[(size_t)r]) != hipSuccess || hipStreamCreateWithFlags(&g->comm[(size_t)r], hipStreamNonBlocking) != hipSuccess)
+      return bail(DR_ERR_DEVICE, "group: cannot create the communication stream");
+    for (int k = 0; k < 2; k++)
+      if (hipEventCreateWithFlags(&g->packed[k][(size_t)r], hipEventDisableTiming) != hipSuccess ||
+          hipEventCreateWithFlags(&g->sent[k][(size_t)r], hipEventDisableTiming) != hipSuccess)
+        return bail(DR_ERR_DEVICE, "group: cannot create events");
+  }
+  if (g->use_rccl) {
+    if (!g->rccl.load()) return bail(DR_ERR_DEVICE, "group: librccl.so not found (set DOGERAY_GROUP_TRANSPORT=copy for peer copies)");
+    g->comms.assign((size_t)n, nullptr);
+    ncclResult_t rc = g->rccl.CommInitAll(g->comms.data(), n, g->device.data());
+    if (rc != ncclSuccess) { g->comms.clear(); return bail(DR_ERR_DEVICE, std::string("group: ncclCommInitAll: ") + g->rccl.GetErrorString(rc)); }
+  } else if (n > 1) {
+    for (int r = 1; r < n; r++) {                 // peer copies into rank 0's staging buffer
+      if (g->device[(size_t)r] == g->device[0]) continue;
+      (void)hipSetDevice(g->device[(size_t)r]);
+      (void)hipDeviceEnablePeerAccess(g->device[0], 0);
+    }
+  }
+  *out = g;
+  return DR_OK;
+}
+
+void dr_group_destroy(dr_group* g) {
+  if (!g) return;
+  for (ncclComm_t c : g->comms) if (c) (void)g->rccl.CommDestroy(c);
+  for (int r = 0; r < g->n; r++) {
+    if (r < (int)g->device.size()) (void)hipSetDevice(g->device[(size_t)r]);
+    if (r < (int)g->comm.size() && g->comm[(size_t)r]) { (void)hipStreamSynchronize(g->comm[(size_t)r]); (void)hipStreamDestroy(g->comm[(size_t)r]); }
+    for (int k = 0; k < 2; k++) {
+      if (r < (int)g->packed[k].size() && g->packed[k][(size_t)r]) (void)hipEventDestroy(g->packed[k][(size_t)r]);
+      if (r < (int)g->sent[k].size() && g->sent[k][(size_t)r]) (void)hipEventDestroy(g->sent[k][(size_t)r]);
+    }
+  }
+  if (!g->device.empty()) (void)hipSetDevice(g->device[0]);
+  for (int k = 0; k < 2; k++) if (g->stage[k]) (void)hipFree(g->stage[k]);
+  for (dr_context* c : g->ctx) if (c) dr_context_destroy(c);
+  delete g;
+}
+
+int dr_group_size(const dr_group* g) { return g ? g->n : DR_ERR_INVALID; }
+dr_context* dr_group_context(dr_group* g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->ctx[(size_t)rank] : nullptr; }
+int dr_group_uses_rccl(const dr_group* g) { return g && g->use_rccl ? 1 : 0; }
+
+int dr_group_upload_scene(dr_group* g, const dr_scene* s) {
+  if (!g || !s) { set_error("null argument"); return DR_ERR_INVALID; }
+  g->error.clear();
+  const bool ok = for_all_ranks(g, [&](int r) {
+    if (dr_context_upload_scene(g->ctx[(size_t)r], s) != DR_OK) { g->fail(std::string("upload on rank ") + std::to_string(r) + ": " + dr_last_error()); return false; }
+    return true;
+  });
+  if (!ok) { set_error(g->error); return DR_ERR_DEVICE; }
+  return DR_OK;
+}
+
+int dr_group_accum_reset(dr_group* g, int W, int H) {
+  if (!g || W <= 0 || H <= 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  for (int r = 0; r < g->n; r++)
+    if (dr_accum_reset(g->ctx[(size_t)r], W, H) != DR_OK) return DR_ERR_DEVICE;
+  const size_t stride = (stripe_elems(W, H, g->n, 0) + 3) & ~(size_t)3;          // rank 0 owns the most columns; 16-byte multiple
+  if (g->n > 1 && (stride != g->stage_stride || !g->stage[0])) {
+    if (hipSetDevice(g->device[0]) != hipSuccess) { set_error("group: hipSetDevice"); return DR_ERR_DEVICE; }
+    for (int k = 0; k < 2; k++) {
+      if (g->stage[k]) { (void)hipFree(g->stage[k]); g->stage[k] = nullptr; }
+      if (hipMalloc((void**)&g->stage[k], (size_t)g->n * stride * sizeof(int32_t)) != hipSuccess) { set_error("group: cannot allocate the staging buffer"); return DR_ERR_NOMEM; }
+    }
+    g->stage_stride = stride;
+  }
+  g->W = W; g->H = H;
+  return DR_OK;
+}
+
+int dr_group_render_accumulate(dr_group* g, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
+                               uint64_t seed_stride, int nframes, int gather_every) {
+  if (!g || !settings13 || nframes < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  if (g->W != W || g->H != H) { set_error("call dr_group_accum_reset(W, H) first"); return DR_ERR_INVALID; }
+  if (nframes == 0) return DR_OK;
+  const int every = gather_every > 0 ? gather_every : nframes;
+  g->error.clear();
+  g->meet.aborted = false; g->meet.waiting = 0;
+  const bool ok = for_all_ranks(g, [&](int r) { return rank_work(g, r, settings13, W, H, background, frame_seed, seed_stride, nframes, every); });
+  if (!ok) { set_error("group: " + g->error); return DR_ERR_DEVICE; }
+  return DR_OK;
+}
+
+}  // extern "C"

@@ -65,6 +65,55 @@ class FrameGatherer:
         return self.full
 
 
+class StripeGatherer:
+    """The device path of bench.py --gpus N: the library packs this rank's stripe (dr_accum_pack_stripe, on the context's
+    own stream), torch.distributed gathers the packed buffers to rank 0 (backend nccl = RCCL: R-1 point-to-point
+    transfers into rank 0), and the library writes them into rank 0's accumulator (dr_accum_unpack_stripes, queued on
+    torch's stream behind the gather).  Nothing waits on the host: events order the three stages, two pack buffers and
+    two staging buffers alternate, so the gather of one batch runs beside the rendering of the next."""
+
+    def __init__(self, ctx, W, H, world, rank, device, group=None):
+        import torch
+        self.ctx, self.W, self.H, self.world, self.rank, self.group, self.device = ctx, W, H, world, rank, group, device
+        gx = W // 8
+        run = 8 * H * 3
+        self.stride = ((gx + world - 1) // world) * run              # int32 per rank: the largest stripe (rank 0's); a multiple of 4
+        self.lib_stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=device)
+        self.stage = [torch.empty((world, self.stride), dtype=torch.int32, device=device) for _ in range(2)] if rank == 0 else None
+        self.done = [None, None]                                     # event: the gather that read pack buffer `slot` has finished
+        self.batch = 0
+
+    def gather_async(self):
+        """Queue pack -> gather -> unpack for the frames rendered so far; returns at once."""
+        import torch
+        import torch.distributed as dist
+        if self.world == 1:
+            return
+        slot = self.batch & 1
+        self.batch += 1
+        cur = torch.cuda.current_stream(self.device)
+        if self.done[slot] is not None:
+            self.lib_stream.wait_event(self.done[slot])              # the buffer is packed again only after its last gather
+        ptr, _ = self.ctx.accum_pack_stripe(slot)
+        packed = torch.as_tensor(_DevArray(ptr, self.stride), device=self.device)
+        ev = torch.cuda.Event()
+        ev.record(self.lib_stream)
+        cur.wait_event(ev)                                           # the gather starts when the stripe is packed
+        if self.rank != 0:
+            dist.gather(packed, gather_list=None, dst=0, group=self.group)
+        else:
+            stage = self.stage[slot]
+            dist.gather(packed, gather_list=[stage[r] for r in range(self.world)], dst=0, group=self.group)
+            self.ctx.accum_unpack_stripes(stage.data_ptr(), self.stride * 4, self.world, 1, stream_ptr=cur.cuda_stream)
+        self.done[slot] = torch.cuda.Event()
+        self.done[slot].record(cur)
+
+    def finish(self):
+        import torch
+        self.ctx.synchronize()
+        torch.cuda.synchronize(self.device)
+
+
 def gather_frame(acc, W, H, world, rank, group=None):
     """acc: this rank's int32[W*H*3] accumulator (zeros outside its block columns).
     Returns the assembled int32[W*H*3] frame on rank 0, None elsewhere."""

@@ -162,7 +162,9 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   first), all others keep their natural order (default 1: the above-average tiles; 0: no tile is
  *                   reordered, -1: every tile by cost)
  *   "coop_steps"    once the tile queue is empty, a ray older than this many node steps is finished by all 64
- *                   lanes of its wave together (default 64, 0 = off), in waves with at most "coop_lanes" (8) lanes walking
+ *                   lanes of its wave together (default 16, 0 = off), in waves with at most "coop_lanes" (8) lanes walking;
+ *                   the wide walk uses the kernel build that contains it only for launches with fewer than
+ *                   "coop_tiles_per_wave" (64) tiles per wave -- short launches, whose tail shows
  *   "wide_tree"     tree under the wide walk, read at dr_context_upload_scene: 1 (default) binned surface-area
  *                   heuristic over the leaf boxes, 0 the reference's own topology (K:1745-1861) collapsed 4-way
  * The environment variable DOGERAY_OPTIONS="name=value,..." applies the same at context creation. */
@@ -187,11 +189,49 @@ int dr_render_frame(dr_context* c, const float settings13[13], int W, int H, flo
 int dr_accum_reset(dr_context* c, int W, int H);
 int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H, float background,
                          uint64_t frame_seed, uint64_t seed_stride, int nframes);
+/* The same without the final wait: the launches are queued on the context's stream and the call returns; at most two
+ * such batches are in flight (a third call waits for the first).  dr_context_synchronize waits for everything queued
+ * and brings dr_stats up to date.  Used to overlap the multi-GPU gather of one batch with the rendering of the next. */
+int dr_render_accumulate_async(dr_context* c, const float settings13[13], int W, int H, float background,
+                               uint64_t frame_seed, uint64_t seed_stride, int nframes);
+int dr_context_synchronize(dr_context* c);
+/* The HIP stream (hipStream_t) every launch of this context is queued on, for callers that order their own device work
+ * (a collective on packed stripes) against it with events. */
+int dr_context_stream(dr_context* c, void** hip_stream);
 int dr_accum_read(dr_context* c, int32_t* out_int3 /* W*H*3 */);
 /* The display divide of K:2287: rgb8[(y*W + x)*3 + ch] = clamp(acc / divide_by, 0, 255). */
 int dr_accum_present(dr_context* c, int divide_by, uint8_t* out_rgb8 /* W*H*3, row-major */);
 /* Device address of the accumulator (int32[W*H*3]) for device-side gathers (RCCL). */
 int dr_accum_device_ptr(dr_context* c, void** dev_ptr, uint64_t* bytes);
+/* Multi-GPU gather, device side.  The framebuffer is column-major (K:1006), so one 8-pixel block column is one
+ * contiguous run of 8*H*3 int32 and a context's stripe (dr_context_set_stripe: columns rem, rem+mod, ...) packs into
+ * [ncols][8*H*3].  dr_accum_pack_stripe queues that copy on the context's stream into one of two library-owned
+ * buffers (slot 0/1: pack batch k+1 while batch k is still being sent) and returns its device address and size.
+ * dr_accum_unpack_stripes, on the gathering rank, copies the packed stripes of ranks first_rank .. world-1 (rank r's at
+ * packed_dev + r * rank_stride_bytes, rank_stride_bytes a multiple of 16) into its own accumulator's columns
+ * r, r+world, ..., on hip_stream (NULL: the context's stream).  Ranks render disjoint columns, so the unpack may run
+ * beside the gathering rank's own rendering. */
+int dr_accum_pack_stripe(dr_context* c, int slot, void** dev_ptr, uint64_t* bytes);
+int dr_accum_unpack_stripes(dr_context* c, const void* packed_dev, uint64_t rank_stride_bytes, int world, int first_rank,
+                            void* hip_stream);
+
+/* ------------------------------------------------------------------ multi-GPU group ----- */
+/* One process, one context and one host thread per GPU (the reference is single-device, K:2614-2615).  Rank r of n
+ * renders the block columns bx % n == r of every frame (scene replicated); every `gather_every` frames each rank packs
+ * its stripe and sends it to rank 0 over RCCL (ncclSend / grouped ncclRecv on a second stream per rank), double-
+ * buffered so that the gather of one batch runs beside the rendering of the next.  After the call rank 0's accumulator
+ * (dr_group_context(g, 0): dr_accum_read / dr_accum_present) holds the assembled sum of all frames.
+ * device_ordinals NULL = 0 .. n-1.  Ranks that share a device, or DOGERAY_GROUP_TRANSPORT=copy, use peer copies. */
+typedef struct dr_group dr_group;
+int dr_group_create(int n, const int* device_ordinals, dr_group** out);
+void dr_group_destroy(dr_group* g);
+int dr_group_size(const dr_group* g);
+int dr_group_uses_rccl(const dr_group* g);
+dr_context* dr_group_context(dr_group* g, int rank);
+int dr_group_upload_scene(dr_group* g, const dr_scene* s);
+int dr_group_accum_reset(dr_group* g, int W, int H);
+int dr_group_render_accumulate(dr_group* g, const float settings13[13], int W, int H, float background,
+                               uint64_t frame_seed, uint64_t seed_stride, int nframes, int gather_every);
 
 /* Counters and timings since the last dr_stats_reset.  Ray = one hit() call (K:800). */
 typedef struct dr_stats {
@@ -212,6 +252,11 @@ typedef struct dr_stats {
 int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the kernel; off by default */
 int dr_stats_reset(dr_context* c);
 int dr_stats_get(dr_context* c, dr_stats* out);
+
+/* Measurement aid (bench.py `roofline.gather`): rate at which this GPU serves divergent, dependent fetches of 64-byte
+ * records from the RESIDENT wide-walk array -- the walk's memory behaviour without its arithmetic.  hot_records
+ * restricts the random walk to the first records of the array (0 = all of it). */
+int dr_context_probe_gather(dr_context* c, uint32_t hot_records, int iters, double* records_per_s);
 
 /* ------------------------------------------------------------------ known-answer hooks -- */
 /* Run single device functions on caller data (host pointers), for parity tests. */

@@ -1,0 +1,124 @@
+"""The multi-GPU path's device pieces on ONE GPU: stripe pack / unpack kernels against numpy, the asynchronous accumulate,
+and the whole dr_group pipeline (one context + one host thread per rank, double-buffered gather beside rendering) with
+several ranks sharing the device (peer-copy transport; RCCL needs distinct GPUs and first runs in the driver's scaling bench)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dr():
+    import dogeray_amd
+    assert dogeray_amd.device_count() >= 1
+    return dogeray_amd
+
+
+@pytest.fixture(scope="module")
+def scene(dr, synth):
+    sc = dr.Scene.load(os.path.join(synth["dir"], "city_small.rts"))
+    sc.build_bvh()
+    return sc
+
+
+W, H = 328, 200        # 41 block columns: not a multiple of 2, 3 or 8; 25 block rows
+
+
+def _dev_tensor(dr, ptr, nelems):
+    import torch
+    from dogeray_amd import multigpu
+    return torch.as_tensor(multigpu._DevArray(ptr, nelems), device=torch.device("cuda", 0))
+
+
+@pytest.mark.parametrize("R", [2, 3, 8])
+def test_pack_and_unpack_against_numpy(dr, scene, R):
+    import torch
+    s = scene.settings()
+    st = dr.pack_settings13(s, 1)
+    ctx = dr.Context(0).upload(scene)
+    ctx.accum_reset(W, H)
+    ctx.render_accumulate(st, W, H, s.background, 5, 1000003, 3)
+    full = ctx.accum_read()                                   # [W, H, 3]
+    gx, run = W // 8, 8 * H * 3
+    cols = full.reshape(-1)[: gx * run].reshape(gx, run)
+    stride = ((gx + R - 1) // R) * run
+    stage = np.zeros((R, stride), dtype=np.int32)
+    for r in range(R):
+        ctx.set_stripe(R, r)
+        ptr, nbytes = ctx.accum_pack_stripe(r & 1)
+        ctx.synchronize()
+        want = cols[r::R]
+        assert nbytes == want.size * 4
+        got = _dev_tensor(dr, ptr, want.size).cpu().numpy().reshape(want.shape)
+        assert np.array_equal(got, want), (R, r)
+        stage[r, : want.size] = want.reshape(-1)
+    # unpack: ranks 1..R-1 from a staging buffer into an accumulator that holds only rank 0's columns
+    ctx.set_stripe(R, 0)
+    ctx.accum_reset(W, H)
+    ctx.render_accumulate(st, W, H, s.background, 5, 1000003, 3)
+    mine = ctx.accum_read()
+    assert not mine.reshape(-1)[: gx * run].reshape(gx, run)[1::R].any() or R == 1
+    dev = torch.from_numpy(stage).cuda()
+    ctx.accum_unpack_stripes(dev.data_ptr(), stride * 4, R, 1)
+    ctx.synchronize()
+    assert np.array_equal(ctx.accum_read(), full), R
+    ctx.close()
+
+
+def test_async_accumulate_equals_blocking(dr, scene):
+    s = scene.settings()
+    st = dr.pack_settings13(s, 1)
+    ctx = dr.Context(0).upload(scene)
+    ctx.accum_reset(W, H)
+    ctx.render_accumulate(st, W, H, s.background, 9, 1000003, 7)
+    want = ctx.accum_read()
+    ctx.accum_reset(W, H)
+    ctx.stats_reset()
+    for k, n in ((0, 2), (2, 3), (5, 1), (6, 1)):              # four batches: the third call waits for the first
+        ctx.render_accumulate_async(st, W, H, s.background, 9 + k * 1000003, 1000003, n)
+    ctx.synchronize()
+    assert np.array_equal(ctx.accum_read(), want)
+    stats = ctx.stats()
+    assert stats["frames"] == 7 and stats["kernel_ms"] > 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("ranks,every", [(1, 0), (2, 2), (3, 1), (3, 4), (8, 3)])
+def test_group_on_one_device_assembles_the_frame(dr, scene, ranks, every):
+    """dr_group with `ranks` contexts on device 0: the frame assembled on rank 0 is the single-context frame, bit for bit."""
+    s = scene.settings()
+    st = dr.pack_settings13(s, 1)
+    ctx = dr.Context(0).upload(scene)
+    ctx.accum_reset(W, H)
+    ctx.render_accumulate(st, W, H, s.background, 31, 1000003, 9)
+    want = ctx.accum_read()
+    ctx.close()
+    g = dr.Group([0] * ranks).upload(scene)
+    assert g.size == ranks and not g.uses_rccl
+    g.accum_reset(W, H)
+    g.render_accumulate(st, W, H, s.background, 31, 1000003, 5, gather_every=every)
+    g.render_accumulate(st, W, H, s.background, 31 + 5 * 1000003, 1000003, 4, gather_every=every)     # accumulates on top
+    assert np.array_equal(g.accum_read(), want), (ranks, every)
+    g.close()
+
+
+def test_native_host_application_with_gpus(dr, synth, tmp_path):
+    """csrc/dogeray_main.cpp --gpus 3 (three ranks on this GPU): the image equals the one-GPU run's."""
+    exe = os.path.join(ROOT, "dogeray_amd", "bin", "dogeray")
+    scene = os.path.join(synth["dir"], "city_small.rts")
+    outs = []
+    for gpus in (1, 3):
+        out = str(tmp_path / ("img%d.ppm" % gpus))
+        env = dict(os.environ, DOGERAY_GROUP_DEVICES="0,0,0")
+        cmd = [exe, scene, "--textures", synth["tex"], "--frames", "12", "--group", "5", "--gather-every", "2", "--out", out, "--quiet"]
+        if gpus > 1:
+            cmd += ["--gpus", str(gpus)]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000

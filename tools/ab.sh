@@ -3,11 +3,11 @@
 VARS=$1; shift
 mkdir -p gpurun_out
 for v in $VARS; do
-  DOGERAY_OPTIONS=$v python3 bench.py --steps ${STEPS:-16} --warmup ${WARM:-2} --no-cpu-baseline --no-traffic "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
+  DOGERAY_OPTIONS=$v python3 bench.py --steps ${STEPS:-16} --warmup ${WARM:-2} --no-cpu-baseline --no-traffic --no-extras --repeats ${REPEATS:-3} "$@" > gpurun_out/ab_$v.json 2> gpurun_out/ab_$v.err || { tail -5 gpurun_out/ab_$v.err; exit 1; }
   python3 - <<PY
 import json
 j=json.loads(open("gpurun_out/ab_$v.json").read().strip().splitlines()[-1])
-print("options $v: %.1f Mrays/s  kernel %.3f ms  frac %.3f  eff node %.3f bounce %.3f" % (j["value"], j["kernel_ms_per_frame"], j["roofline"]["frac"], j["simd_efficiency"]["node_loop"], j["simd_efficiency"]["bounce_loop"]))
+print("options $v: %.1f Mrays/s  kernel %.4f ms/frame (wall %.4f, min %.4f max %.4f)  clock %.0f MHz" % (j["value"], j["kernel_ms_per_frame"], j["ms_per_step"], j["ms_per_step_min"], j["ms_per_step_max"], j["timed_waves"]["shader_clock_mhz"]))
 d=j.get("diag")
 if d and d[2]:
     fr=j["steps"]

@@ -5,7 +5,7 @@ VARS=$1; ROUNDS=${2:-3}; shift; shift
 for r in $(seq 1 $ROUNDS); do
   for v in $VARS; do
     if [ "$v" = default ]; then unset DOGERAY_AMD_LIB; else export DOGERAY_AMD_LIB=$PWD/tools/_exp/lib_$v.so; fi
-    python3 bench.py --steps ${STEPS:-64} --warmup 8 --no-cpu-baseline --no-traffic "$@" 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('$v', round(j['kernel_ms_per_frame'],4), round(j['value'],1), 'clock %.0f MHz' % j['timed_waves']['shader_clock_mhz'], 'wave-cycles/frame %.4g' % j['timed_waves']['wave_cycles_per_frame'])"
+    python3 bench.py --steps ${STEPS:-32} --warmup 8 --no-cpu-baseline --no-traffic --no-extras --repeats ${REPEATS:-5} "$@" 2>/dev/null | python3 -c "import json,sys; j=json.loads(sys.stdin.read()); print('$v', round(j['kernel_ms_per_frame'],4), round(j['value'],1), 'clock %.0f MHz' % j['timed_waves']['shader_clock_mhz'], 'wave-cycles/frame %.4g' % j['timed_waves']['wave_cycles_per_frame'])"
   done
 done | tee /tmp/ab_libs.txt
 python3 - <<'PY'
