@@ -79,6 +79,7 @@ class StripeGatherer:
         run = 8 * H * 3
         self.stride = ((gx + world - 1) // world) * run              # int32 per rank: the largest stripe (rank 0's); a multiple of 4
         self.lib_stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=device)
+        self.coll_stream = torch.cuda.Stream(device=device)          # the collective and the unpack run here (a real stream: its handle is not 0)
         self.stage = [torch.empty((world, self.stride), dtype=torch.int32, device=device) for _ in range(2)] if rank == 0 else None
         self.done = [None, None]                                     # event: the gather that read pack buffer `slot` has finished
         self.batch = 0
@@ -91,7 +92,7 @@ class StripeGatherer:
             return
         slot = self.batch & 1
         self.batch += 1
-        cur = torch.cuda.current_stream(self.device)
+        cur = self.coll_stream
         if self.done[slot] is not None:
             self.lib_stream.wait_event(self.done[slot])              # the buffer is packed again only after its last gather
         ptr, _ = self.ctx.accum_pack_stripe(slot)
@@ -99,12 +100,13 @@ class StripeGatherer:
         ev = torch.cuda.Event()
         ev.record(self.lib_stream)
         cur.wait_event(ev)                                           # the gather starts when the stripe is packed
-        if self.rank != 0:
-            dist.gather(packed, gather_list=None, dst=0, group=self.group)
-        else:
-            stage = self.stage[slot]
-            dist.gather(packed, gather_list=[stage[r] for r in range(self.world)], dst=0, group=self.group)
-            self.ctx.accum_unpack_stripes(stage.data_ptr(), self.stride * 4, self.world, 1, stream_ptr=cur.cuda_stream)
+        with torch.cuda.stream(cur):                                 # torch.distributed orders a collective against the current stream
+            if self.rank != 0:
+                dist.gather(packed, gather_list=None, dst=0, group=self.group)
+            else:
+                stage = self.stage[slot]
+                dist.gather(packed, gather_list=[stage[r] for r in range(self.world)], dst=0, group=self.group)
+                self.ctx.accum_unpack_stripes(stage.data_ptr(), self.stride * 4, self.world, 1, stream_ptr=cur.cuda_stream)
         self.done[slot] = torch.cuda.Event()
         self.done[slot].record(cur)
 

@@ -122,3 +122,45 @@ def test_native_host_application_with_gpus(dr, synth, tmp_path):
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         outs.append(open(out, "rb").read())
     assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
+def test_stripe_gatherer_with_a_stand_in_collective(dr, scene, monkeypatch):
+    """multigpu.StripeGatherer (bench.py --gpus N on RCCL) for two ranks in ONE process: torch.distributed.gather is replaced
+    by a copy between the two ranks' buffers (RCCL refuses two ranks on one device), everything else -- pack kernel on the
+    library's stream, event ordering against torch's stream, unpack on torch's stream, buffer alternation -- is the real path."""
+    import torch
+    import torch.distributed as dist
+    from dogeray_amd import multigpu
+    s = scene.settings()
+    st = dr.pack_settings13(s, 1)
+    dev = torch.device("cuda", 0)
+    ref = dr.Context(0).upload(scene)
+    ref.accum_reset(W, H)
+    ref.render_accumulate(st, W, H, s.background, 77, 1000003, 6)
+    want = ref.accum_read()
+    ref.close()
+    ctxs = [dr.Context(0).upload(scene) for _ in range(2)]
+    mailbox = {}
+
+    def fake_gather(tensor, gather_list=None, dst=0, group=None):
+        if gather_list is None:                       # rank 1 "sends": keep a copy made on the current stream
+            mailbox["rank1"] = tensor.clone()
+        else:
+            gather_list[0].copy_(tensor)
+            gather_list[1].copy_(mailbox.pop("rank1"))
+
+    monkeypatch.setattr(dist, "gather", fake_gather)
+    gs = []
+    for r, c in enumerate(ctxs):
+        c.set_stripe(2, r)
+        c.accum_reset(W, H)
+        gs.append(multigpu.StripeGatherer(c, W, H, 2, r, dev))
+    for k in range(3):                                # three batches of two frames: both pack slots and both staging buffers are reused
+        for r in (1, 0):                              # rank 1 first, so that its stripe is in the mailbox when rank 0 gathers
+            ctxs[r].render_accumulate_async(st, W, H, s.background, 77 + 2 * k * 1000003, 1000003, 2)
+            gs[r].gather_async()
+    for g in gs:
+        g.finish()
+    assert np.array_equal(ctxs[0].accum_read(), want)
+    for c in ctxs:
+        c.close()
