@@ -125,6 +125,7 @@ _API = [
     ("dr_kat_sphere", C.c_int, [_VP, C.c_int] + [_VP] * 5),
     ("dr_kat_optics", C.c_int, [_VP, C.c_int] + [_VP] * 6),
     ("dr_kat_hit", C.c_int, [_VP, C.c_int] + [_VP] * 5),
+    ("dr_kat_normal", C.c_int, [_VP, C.c_int] + [_VP] * 6),
 ]
 API_SYMBOLS = [a[0] for a in _API]
 
@@ -423,6 +424,16 @@ class Context:
         sch = np.zeros(n, dtype=np.float32)
         _check(lib().dr_kat_optics(self._h, n, _p(v), _p(nrm), _p(eta), _p(refl), _p(refr), _p(sch)))
         return refl, refr, sch
+
+    def kat_normal(self, obj_index, o, d, t):
+        """getnormal K:703-773: (normal[n, 3] before the facing flip, texco[n, 3]) for hits of rays (o, d) at t on objects obj_index."""
+        idx = np.ascontiguousarray(obj_index, dtype=np.int32)
+        o, d, t = _f32(o), _f32(d), _f32(t)
+        n = idx.shape[0]
+        nrm = np.zeros((n, 3), dtype=np.float32)
+        tc = np.zeros((n, 3), dtype=np.float32)
+        _check(lib().dr_kat_normal(self._h, n, _p(idx), _p(o), _p(d), _p(t), _p(nrm), _p(tc)))
+        return nrm, tc
 
     def kat_hit(self, o, d, want_visits=False):
         o, d = _f32(o), _f32(d)

@@ -546,6 +546,18 @@ __global__ void kat_optics_kernel(int n, const float* v, const float* nrm, const
   refr[3 * i] = r2.x; refr[3 * i + 1] = r2.y; refr[3 * i + 2] = r2.z;
   sch[i] = reflectance(a.x, eta[i]);
 }
+__global__ void kat_normal_kernel(RenderParams P, int n, const int32_t* slot, const float* o, const float* d, const float* t, float* nrm, float* texco) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4* pp = reinterpret_cast<const float4*>(P.prims + slot[i]);
+  const float4* sp = reinterpret_cast<const float4*>(P.shade + slot[i]);
+  const V3 ro = ld3(o + 3 * i), rd = ld3(d + 3 * i);
+  const V3 hitpoint = ro + splat(t[i]) * rd;                           // K:806
+  V3 tc;
+  const V3 N = surface_normal(pp[0], pp[1], pp[2], sp[0], sp[1], sp[2], sp[3], sp[4], sp[6], ro, rd, hitpoint, tc);
+  nrm[3 * i] = N.x; nrm[3 * i + 1] = N.y; nrm[3 * i + 2] = N.z;
+  texco[3 * i] = tc.x; texco[3 * i + 1] = tc.y; texco[3 * i + 2] = tc.z;
+}
 template <int MODE>
 __global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, const float* o, const float* d, float* t, int32_t* slot, int32_t* visits) {
   __shared__ int lds_stack[MODE == DR_TRAVERSAL_ORDERED ? ORDERED_STACK * 256 : (MODE == DR_TRAVERSAL_WIDE ? WIDE_STACK * 256 : 1)];
@@ -1352,6 +1364,28 @@ int dr_kat_optics(dr_context* c, int n, const float* v, const float* nrm, const 
   HIP_TRY(hipStreamSynchronize(c->stream));
   KAT_DO(b1.get(refl, m)); KAT_DO(b2.get(refr, m));
   return b3.get(schlick, (size_t)n);
+}
+
+int dr_kat_normal(dr_context* c, int n, const int32_t* object_index, const float* o, const float* d, const float* t, float* normal, float* texco) {
+  KAT_PRE(n);
+  if (!c->walk || !object_index || !o || !d || !t || !normal || !texco) { set_error("no scene uploaded, or null argument"); return DR_ERR_INVALID; }
+  std::vector<int32_t> slot_of((size_t)c->n_prims, -1), slots((size_t)n);
+  for (int sidx = 0; sidx < c->n_prims; sidx++) slot_of[(size_t)c->slot_to_orig[(size_t)sidx]] = sidx;
+  for (int i = 0; i < n; i++) {
+    if (object_index[i] < 0 || object_index[i] >= c->n_prims) { set_error("object index out of range"); return DR_ERR_INVALID; }
+    slots[(size_t)i] = slot_of[(size_t)object_index[i]];
+  }
+  DevBuf<int32_t> bs; DevBuf<float> bo, bd, bt, bn, bc;
+  size_t m = (size_t)n * 3;
+  KAT_DO(bs.alloc((size_t)n)); KAT_DO(bo.alloc(m)); KAT_DO(bd.alloc(m)); KAT_DO(bt.alloc((size_t)n)); KAT_DO(bn.alloc(m)); KAT_DO(bc.alloc(m));
+  KAT_DO(bs.put(slots.data(), (size_t)n)); KAT_DO(bo.put(o, m)); KAT_DO(bd.put(d, m)); KAT_DO(bt.put(t, (size_t)n));
+  RenderParams P;
+  memset(&P, 0, sizeof(P));
+  P.prims = c->prims; P.shade = c->shade;
+  hipLaunchKernelGGL(kat_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c->stream, P, n, bs.p, bo.p, bd.p, bt.p, bn.p, bc.p);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  KAT_DO(bn.get(normal, m));
+  return bc.get(texco, m);
 }
 
 int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx, int32_t* visits) {

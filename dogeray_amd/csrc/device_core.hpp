@@ -753,25 +753,14 @@ __device__ __forceinline__ V3 rgb_of(uint32_t px) {
   return mk(float(px & 255u) / 255, float((px >> 8) & 255u) / 255, float((px >> 16) & 255u) / 255);
 }
 
-// raycolor K:787-982 is split at its natural seams so that the per-pixel kernel and the
-// persistent kernel run the same arithmetic: shade_hit = the "hit > 0" branch of one bounce
-// (K:807-950), shade_miss = the background branch (K:951-976).
-struct Path { V3 rayo, raydir, atten; };
-
-// Returns true when the path continues (rayo/raydir/atten updated), false when it ends at an
-// emissive surface with `emitted` as its radiance (K:941-944).
-template <bool COUNT>
-__device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, float t, int slot, Xorwow& rng, Ctr& c, V3& emitted) {
-  V3& rayo = path.rayo; V3& raydir = path.raydir; V3& atten = path.atten;
-  if (COUNT) c.S++;
-  V3 hitpoint = rayo + splat(t) * raydir;
-  // ---- getnormal K:703-773
-  const float4* pp = reinterpret_cast<const float4*>(P.prims + slot);
-  const float4* sp = reinterpret_cast<const float4*>(P.shade + slot);
-  float4 pA = pp[0], pB = pp[1], pC = pp[2];
-  float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
+// getnormal K:703-773 on the device records of one primitive (prims: pA..pC, shade: s0..s4, s6): the unflipped normal and the
+// interpolated texture coordinate.  Barycentrics are recomputed from the ray origin, not from the hit point (K:728-745);
+// the file's face normal is used unless its z is the -20 sentinel (then the cross product), vertex normals only when the
+// smooth flag is set and n1.z is not the sentinel; spheres divide by the radius, other types normalise (hit - pos).
+__device__ __forceinline__ V3 surface_normal(float4 pA, float4 pB, float4 pC, float4 s0, float4 s1, float4 s2, float4 s3, float4 s4, float4 s6,
+                                             V3 rayo, V3 raydir, V3 hitpoint, V3& texco) {
   int type = __float_as_int(pC.y);
-  V3 texco = mk(0, 0, 0);
+  texco = mk(0, 0, 0);
   V3 N;
   if (type == 0) {
     N = (hitpoint - mk(pA.x, pA.y, pA.z)) / splat(pA.w);
@@ -802,6 +791,27 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, flo
   } else {
     N = normalized(hitpoint - mk(pA.x, pA.y, pA.z));
   }
+  return N;
+}
+
+// raycolor K:787-982 is split at its natural seams so that the per-pixel kernel and the
+// persistent kernel run the same arithmetic: shade_hit = the "hit > 0" branch of one bounce
+// (K:807-950), shade_miss = the background branch (K:951-976).
+struct Path { V3 rayo, raydir, atten; };
+
+// Returns true when the path continues (rayo/raydir/atten updated), false when it ends at an
+// emissive surface with `emitted` as its radiance (K:941-944).
+template <bool COUNT>
+__device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, float t, int slot, Xorwow& rng, Ctr& c, V3& emitted) {
+  V3& rayo = path.rayo; V3& raydir = path.raydir; V3& atten = path.atten;
+  if (COUNT) c.S++;
+  V3 hitpoint = rayo + splat(t) * raydir;
+  const float4* pp = reinterpret_cast<const float4*>(P.prims + slot);
+  const float4* sp = reinterpret_cast<const float4*>(P.shade + slot);
+  float4 pA = pp[0], pB = pp[1], pC = pp[2];
+  float4 s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5], s6 = sp[6];
+  V3 texco;
+  V3 N = surface_normal(pA, pB, pC, s0, s1, s2, s3, s4, s6, rayo, raydir, hitpoint, texco);
   bool front = dot(raydir, N) < 0;
   N = front ? N : N * splat(-1.0f);
   // ---- material inputs K:826-844

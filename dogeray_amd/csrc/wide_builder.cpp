@@ -44,7 +44,10 @@ struct BNode {          // binary tree: children < 0 encode a leaf (~slot)
   int child[2];
 };
 
-constexpr int BINS = 16;
+#ifndef DR_WIDE_BINS
+#define DR_WIDE_BINS 16
+#endif
+constexpr int BINS = DR_WIDE_BINS;
 constexpr int MAX_BINARY_DEPTH = 2 * WIDE_MAX_DEPTH;     // a 2-levels-per-node collapse then fits the kernel's stack
 
 struct SahBuilder {

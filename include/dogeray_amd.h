@@ -269,6 +269,10 @@ int dr_kat_sphere(dr_context* c, int n, const float* o, const float* d, const fl
                   const float* radius, float* t);
 int dr_kat_optics(dr_context* c, int n, const float* v, const float* nrm, const float* eta, float* refl,
                   float* refr, float* schlick);
+/* getnormal K:703-773 for object `object_index[i]` (index in the .rts file) of the resident scene, ray (o, d), hit at t:
+ * the normalised, not yet flipped normal and the interpolated texture coordinate (z = 0), 3 floats each */
+int dr_kat_normal(dr_context* c, int n, const int32_t* object_index, const float* o, const float* d, const float* t,
+                  float* normal, float* texco);
 /* closest hit against the resident scene: t (-1 = miss), ORIGINAL object index and (visits may be NULL)
  * the number of boxes the chosen traversal tested for that ray */
 int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx, int32_t* visits);

@@ -1004,6 +1004,19 @@ void orc_kat_hit(void* h, int n, const float* o, const float* d, float* t, int32
   }
 }
 // scatter helpers: in v[3n], nrm[3n], eta[n] -> reflect[3n], refract[3n], schlick[n] (cosine = v.x)
+// getnormal K:703-773 as called from raycolor K:806-808: hitpoint = origin + t * dir, texco starts at 0 (C6)
+void orc_kat_normal(void* h, int n, const int32_t* obj, const float* o, const float* d, const float* t, float* nrm, float* texco) {
+  const Scene& s = *(Scene*)h;
+  for (int i = 0; i < n; i++) {
+    V3 ro = v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), rd = v3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    V3 hp = ro + splat(t[i]) * rd;
+    V3 tc = v3(0, 0, 0);
+    V3 N = getnormal(s, obj[i], ro, hp, rd, tc);
+    nrm[3 * i] = N.x; nrm[3 * i + 1] = N.y; nrm[3 * i + 2] = N.z;
+    texco[3 * i] = tc.x; texco[3 * i + 1] = tc.y; texco[3 * i + 2] = tc.z;
+  }
+}
+
 void orc_kat_optics(int n, const float* v, const float* nrm, const float* eta, float* refl, float* refr, float* schlick) {
   for (int i = 0; i < n; i++) {
     V3 a = v3(v[3*i], v[3*i+1], v[3*i+2]), b = v3(nrm[3*i], nrm[3*i+1], nrm[3*i+2]);

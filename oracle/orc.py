@@ -83,6 +83,7 @@ def lib(variant=""):
     L.orc_kat_tri.argtypes = [C.c_int] + [C.c_void_p] * 6
     L.orc_kat_sphere.argtypes = [C.c_int] + [C.c_void_p] * 5
     L.orc_kat_hit.argtypes = [vp, C.c_int] + [C.c_void_p] * 4
+    L.orc_kat_normal.argtypes = [vp, C.c_int] + [C.c_void_p] * 6
     L.orc_kat_optics.argtypes = [C.c_int] + [C.c_void_p] * 6
     _libs[name] = L
     return L
@@ -172,6 +173,15 @@ class Scene:
         if rc != 0:
             raise RuntimeError(self.L.orc_last_error().decode())
         return out, c.as_dict(), vis
+
+    def kat_normal(self, obj_index, o, d, t):
+        idx = np.ascontiguousarray(obj_index, dtype=np.int32)
+        o, d, t = _f32(o), _f32(d), _f32(t)
+        n = idx.shape[0]
+        nrm = np.zeros((n, 3), dtype=np.float32)
+        tc = np.zeros((n, 3), dtype=np.float32)
+        self.L.orc_kat_normal(self.h, n, _p(idx), _p(o), _p(d), _p(t), _p(nrm), _p(tc))
+        return nrm, tc
 
     def kat_hit(self, o, d):
         o, d = _f32(o), _f32(d)

@@ -171,3 +171,40 @@ def test_other_configs_full_size(other_scenes, synth, name, gen_args, Wc, Hc, te
     print("%s: %.6f of sampled pixels identical to the oracle" % (name, same))
     assert same == 1.0
     ctx.close()
+
+
+def test_c3_bolter2_with_its_textures_at_1920x1080(tmp_path):
+    """SURVEY 8(d) C3 as specified: samples/bolter2.blend.rts (3 892 triangles, 37 columns) with samples/boltersmall.ppm
+    (1000x1000) and samples/env.ppm (800x600) at 1920x1080 -- the fixtures of tests/golden/reference_image -- default
+    kernel + wide walk against the tile kernel and the threaded walk, accumulation, and the oracle on every 12th block column."""
+    import dogeray_amd as dr
+    import reference_image as ri
+    from oracle import orc
+    path, texdir = ri.bolter_scene(tmp_path)
+    scene = dr.Scene.load(path, texdir)
+    assert scene.num_objects == 3892 and len(scene.textures()) == 2
+    scene.build_bvh()
+    s = scene.settings()
+    assert s.backtex >= 0
+    Wc, Hc = 1920, 1080
+    ctx = dr.Context(0).upload(scene)
+    st = dr.pack_settings13(s, 1)
+    a = ctx.render_frame(st, Wc, Hc, s.background, 2024)
+    ctx.set_traversal(0)
+    assert np.array_equal(a, ctx.render_frame(st, Wc, Hc, s.background, 2024))
+    ctx.set_option("kernel", 0)
+    assert np.array_equal(a, ctx.render_frame(st, Wc, Hc, s.background, 2024))
+    ctx.set_option("kernel", 1)
+    ctx.set_traversal(2)
+    ctx.accum_reset(Wc, Hc)
+    ctx.render_accumulate(st, Wc, Hc, s.background, 2024, 1000003, 3)
+    acc = ctx.accum_read().astype(np.int64)
+    assert np.array_equal(acc - a, sum(ctx.render_frame(st, Wc, Hc, s.background, 2024 + 1000003 * k).astype(np.int64) for k in (1, 2)))
+    osc = orc.Scene(path, texdir)
+    osc.build_bvh()
+    ref, rc = osc.render(st, Wc, Hc, s.background, 2024, nthreads=os.cpu_count() or 8, col_mod=12, col_rem=7)
+    cols = (np.arange(Wc) // 8) % 12 == 7
+    same = float(np.all(a[cols] == ref[cols], axis=2).mean())
+    print("C3 bolter2 1920x1080: %.6f of sampled pixels identical to the oracle, %d texel fetches on the sample" % (same, rc["T"]))
+    assert same == 1.0 and rc["T"] > 10000
+    ctx.close()

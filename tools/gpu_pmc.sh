@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 i=0
 for grp in "$@"; do
   i=$((i+1))
-  timeout -k 10 150 rocprofv3 --pmc $grp -d $OUT/p$i -o pmc --output-format csv -- python3 bench.py --steps 32 --warmup 32 --no-cpu-baseline --no-traffic > /dev/null 2> $OUT/p$i.err || { tail -3 $OUT/p$i.err; echo "pass $i failed: $grp"; }
+  timeout -k 10 150 rocprofv3 --pmc $grp -d $OUT/p$i -o pmc --output-format csv -- python3 bench.py --steps 32 --warmup 32 --repeats 1 --no-cpu-baseline --no-traffic --no-extras > /dev/null 2> $OUT/p$i.err || { tail -3 $OUT/p$i.err; echo "pass $i failed: $grp"; }
 done
 python3 - <<PY
 import csv, glob, os

@@ -37,6 +37,6 @@ for name in ("bench_plain.json", "bench_trace.json"):
     f = os.path.join(d, name)
     if os.path.exists(f) and os.path.getsize(f):
         j = json.loads(open(f).read().strip().splitlines()[-1])
-        out.append("== %s: value=%.1f %s ms_per_step=%.3f kernel_ms=%.3f roofline.frac=%.3f" % (
-            name, j["value"], j["unit"], j["ms_per_step"], j["kernel_ms_per_frame"], j["roofline"]["frac"]))
+        out.append("== %s: value=%.1f %s ms_per_step=%.4f kernel_ms_per_frame=%.4f launch_ms=%.3f frames_per_launch=%.0f" % (
+            name, j["value"], j["unit"], j["ms_per_step"], j["kernel_ms_per_frame"], j["roofline"]["launch_ms"], j["roofline"]["frames_per_launch"]))
 print("\n".join(out))
