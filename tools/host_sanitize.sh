@@ -1,12 +1,12 @@
 #!/bin/bash
-# Host C++ (reader, BVH builder, lineariser, .rtsb) under AddressSanitizer + UBSan on fuzzed, malformed and golden
-# scenes (GPU sanitizers are not available on the pool; the device code is covered by the parity tests instead).
+# Host C++ (reader, BVH builder, lineariser, wide-walk builder, .rtsb) under AddressSanitizer + UBSan on fuzzed, malformed
+# and golden scenes, plus BVH arrays with corrupted links (as a hand-made .rtsb or a caller's arrays could carry) (GPU sanitizers are not available on the pool; the device code is covered by the parity tests instead).
 # usage: tools/host_sanitize.sh      (from the repo root; exits non-zero on any finding)
 set -e
 D=${TMPDIR:-/tmp}/dogeray_asan; rm -rf $D; mkdir -p $D/sc
 g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -ffp-contract=off \
     -I dogeray_amd/csrc -I include -o $D/drv tools/host_sanitize_driver.cpp \
-    dogeray_amd/csrc/linearise.cpp dogeray_amd/csrc/rts_reader.cpp dogeray_amd/csrc/bvh_builder.cpp dogeray_amd/csrc/capi_host.cpp -pthread
+    dogeray_amd/csrc/linearise.cpp dogeray_amd/csrc/wide_builder.cpp dogeray_amd/csrc/rts_reader.cpp dogeray_amd/csrc/bvh_builder.cpp dogeray_amd/csrc/capi_host.cpp -pthread
 python3 - "$D" <<'PY'
 import sys, os, numpy as np
 sys.path.insert(0, 'tests')
