@@ -388,6 +388,243 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   }
 }
 
+// Two paths per lane (wide walk, long launches).
+//
+// In the kernel above a lane owns ONE path: when its walk ends it idles until the wave's next shade/refill phase, and a
+// phase runs as soon as half the lanes idle -- measured on the bench scene, a node step executes for 26 of 64 lanes and a
+// phase shades 34.  Here every lane owns TWO paths (records in a per-wave region of global memory, 112 bytes each): while
+// one is walked (its ray, stack and best hit in registers, nothing else), the other waits to be shaded or holds the next
+// ray, already made.  A walk that ends leaves (t, slot) in its record and the lane starts on its other path at once; the
+// phase runs when THRESH lanes have a path to service (or nobody can walk) and shades ONE path of every such lane -- at
+// 48-64 lanes instead of 34, and the node loop keeps nearly all lanes.  The arithmetic of a path is untouched (same
+// functions, same order of draws), which lane or slot carries it does not enter it: frames are identical to the other
+// kernels'.  Option "paired" = 1 selects it for launches with many tiles per wave.  MEASURED (bench scene, 32 frames per launch):
+// node steps run for 34 lanes instead of 26 and a phase serves 41 paths instead of 34, but the lanes that wait at leaves
+// are as many as before, the records travel through memory and the phase spills (96 VGPRs + 88 bytes of scratch):
+// 0.86 ms/frame against 0.69.  Kept as an option, off by default.
+constexpr int PATH_UNITS = 7;             // 16-byte units per path record
+constexpr int PAIR_STASH = 12;
+constexpr int PAIR_IDLE_MAX = 16;         // ... or as soon as this many lanes have nothing to walk            // dwords per lane stashed during a phase (behind the WIDE_STACK stack words)
+enum { PS_EMPTY = 0, PS_READY = 1, PS_WALK = 2, PS_DONE = 3, PS_RETIRED = 4 };
+
+template <int OCC, int THRESH, int PARK_MIN, int P_UNROLL>
+__global__ __launch_bounds__(256, OCC) void render_paired_kernel(RenderParams P, unsigned* tile_counter, const int* __restrict__ tile_order,
+                                                                 const int* __restrict__ region_start, unsigned* __restrict__ pixel_cost,
+                                                                 float4* __restrict__ paths) {
+  const int lane = threadIdx.x & 63;
+  const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
+  constexpr int REGION = (WIDE_STACK + PAIR_STASH) * 64;
+  __shared__ int wave_lds[4 * REGION];
+  int* const my_lds = wave_lds + (threadIdx.x >> 6) * REGION;
+  int* const my_stack = my_lds + lane;
+  float* const st = reinterpret_cast<float*>(my_lds) + WIDE_STACK * 64 + lane;
+  float4* const my_paths = paths + ((size_t)wave_id * 64 + (size_t)lane) * 2 * PATH_UNITS;   // this lane's two records
+  const int ntiles = P.ncols * P.gy;
+  const WalkRsrc walk = wide_rsrc(P);
+  Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cur_tile = ntiles, cur_frame = 0, cur_next = 64;
+  int region = 0, regions_left = P.regions;
+  if (P.regions > 1) region = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % (unsigned)P.regions);   // HW_REG_XCC_ID
+  // the walking path: ray, traversal state, steps of this ray
+  Trav tr; tr.node = -1; tr.best_t = 0; tr.best_slot = -1;
+  WideStack ws; ws.top = 0u; ws.sp = 0;
+  V3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), inv = mk(0, 0, 0);
+  WideRay wr; wr.inv = wr.marg = mk(0, 0, 0);
+  unsigned wsteps = 0;
+  int cur = -1;                           // slot being walked, -1 none
+  int st0 = PS_EMPTY, st1 = PS_EMPTY;     // state of this lane's two paths
+  V3 so = mk(0, 0, 0), sd = mk(0, 0, 0);  // the ray of the path that is PS_READY (at most one: a lane that is not walking starts on it at once)
+  const unsigned long long t_begin = __builtin_readcyclecounter(), r_begin = __builtin_amdgcn_s_memrealtime();
+  unsigned n_iter = 0, n_phase = 0, n_nodestep = 0, n_leafstep = 0, n_served = 0;      // wave-level tallies (scalar registers), written once at the end
+  for (;;) {
+    n_iter++;
+    // ---- a walk that has ended leaves its hit in the record; the lane turns to its other path if that has a ray
+    if (cur >= 0 && tr.node == -1) {
+      float* rec = reinterpret_cast<float*>(my_paths + cur * PATH_UNITS);
+      rec[6] = tr.best_slot < 0 ? -1.0f : tr.best_t;
+      rec[7] = __int_as_float(tr.best_slot);
+      rec[26] = __uint_as_float(wsteps);
+      if (cur == 0) st0 = PS_DONE; else st1 = PS_DONE;
+      cur = -1;
+    }
+    if (cur < 0 && (st0 == PS_READY || st1 == PS_READY)) {
+      cur = st0 == PS_READY ? 0 : 1;
+      if (cur == 0) st0 = PS_WALK; else st1 = PS_WALK;
+      wo = so; wd = sd;
+      inv = mk(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+      wr = wide_ray(wo, inv, P.wide_pmax);
+      trav_begin(tr);
+      ws.top = 0u; ws.sp = 0;
+      wsteps = 0;
+    }
+    const bool serviceable0 = st0 == PS_DONE || st0 == PS_EMPTY, serviceable1 = st1 == PS_DONE || st1 == PS_EMPTY;
+    const unsigned long long need = __ballot(serviceable0 || serviceable1);
+    const unsigned long long walking = __ballot(cur >= 0);
+    // a phase when enough lanes have a path to service, or too many lanes have nothing to walk (both their paths wait)
+    if (need != 0ull && ((int)__popcll(need) >= THRESH || (int)__popcll(~walking) >= PAIR_IDLE_MAX || walking == 0ull)) {
+      // ================= phase: one path of every lane that has one to service
+      const int s = serviceable0 ? 0 : (serviceable1 ? 1 : -1);
+      n_phase++; n_served += (unsigned)__popcll(need);
+      {
+        st[0 * 64] = wo.x; st[1 * 64] = wo.y; st[2 * 64] = wo.z; st[3 * 64] = wd.x; st[4 * 64] = wd.y; st[5 * 64] = wd.z;
+        st[6 * 64] = tr.best_t; st[7 * 64] = __int_as_float(tr.best_slot); st[8 * 64] = __int_as_float(tr.node);
+        st[9 * 64] = __uint_as_float(ws.top); st[10 * 64] = __int_as_float(ws.sp); st[11 * 64] = __uint_as_float(wsteps);
+        asm volatile("" ::: "memory");           // the walking path's state waits in LDS: the shading code is where register pressure peaks
+      }
+      float4* const rec = my_paths + (s < 0 ? 0 : s) * PATH_UNITS;
+      const int sstate = s == 0 ? st0 : st1;
+      Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
+      V3 color = mk(0, 0, 0);
+      Xorwow rng; rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = rng.d = 0;
+      int px = -1, py = 0, pcode = 0, frame = 0, bounce = 0, sample = 0;
+      unsigned psteps = 0;
+      float hit_t = -1.0f; int hit_slot = -1;
+      const bool shade_me = s >= 0 && sstate == PS_DONE;
+      if (shade_me) {
+        const float4 u0 = rec[0], u1 = rec[1], u2 = rec[2], u3 = rec[3], u4 = rec[4], u5 = rec[5], u6 = rec[6];
+        path.rayo = mk(u0.x, u0.y, u0.z); path.raydir = mk(u0.w, u1.x, u1.y);
+        hit_t = u1.z; hit_slot = __float_as_int(u1.w);
+        path.atten = mk(u2.x, u2.y, u2.z); color = mk(u2.w, u3.x, u3.y);
+        px = __float_as_int(u3.z); py = __float_as_int(u3.w);
+        rng.v0 = __float_as_uint(u4.x); rng.v1 = __float_as_uint(u4.y); rng.v2 = __float_as_uint(u4.z); rng.v3 = __float_as_uint(u4.w);
+        rng.v4 = __float_as_uint(u5.x); rng.d = __float_as_uint(u5.y); pcode = __float_as_int(u5.z);
+        frame = __float_as_int(u5.w) & 0xffff; bounce = __float_as_int(u5.w) >> 16;
+        sample = __float_as_int(u6.x); psteps = __float_as_uint(u6.y) + __float_as_uint(u6.z);
+      }
+      bool between = s >= 0 && sstate == PS_EMPTY;       // has no path: next sample or a new pixel
+      bool has_ray = false;
+      if (shade_me) {
+        bool ended;
+        V3 radiance = mk(0, 0, 0);
+        if (hit_slot >= 0 && hit_t > 0.0f) {
+          ended = !shade_hit<false>(P, path, hit_t, hit_slot, rng, c, radiance);
+          if (!ended) { bounce++; if (bounce >= P.max_depth) ended = true; }        // depth exhausted: black (K:981)
+        } else {
+          radiance = shade_miss<false>(P, path, c);
+          ended = true;
+        }
+        if (ended) { color = color + radiance; sample++; between = true; }
+        else has_ray = true;
+      }
+      bool want_pixel = false;
+      if (between) {
+        if (px >= 0 && (float)sample < P.spp_f) {
+          // same pixel, next sample (K:1059)
+        } else {
+          if (px >= 0) {
+            store_pixel(P, px, py, color);
+            if (pixel_cost) pixel_cost[pcode] = psteps;
+          }
+          px = -1;
+          want_pixel = true;
+        }
+      }
+      unsigned long long ask = __ballot(want_pixel);
+      while (ask != 0ull) {
+        if (cur_next >= 64) {                      // wave-uniform: fetch the next chunk (tile, frame)
+          cur_tile = ntiles;
+          while (regions_left > 0) {
+            const int r0 = region_start ? region_start[region] : P.region_start[region];
+            const int r1 = region_start ? region_start[region + 1] : P.region_start[region + 1];
+            unsigned t = 0;
+            if (lane == 0) t = atomicAdd(tile_counter + region, 1u);
+            const int q = (int)__builtin_amdgcn_readfirstlane(t);
+            if (q < (r1 - r0) * P.batch) {
+              const int tt = q / P.batch;
+              cur_frame = q - tt * P.batch;
+              cur_tile = tile_order ? tile_order[r0 + tt] : r0 + tt;
+              break;
+            }
+            region = region + 1 == P.regions ? 0 : region + 1;   // this band is done: help with the next one
+            regions_left--;
+          }
+          cur_next = 0;
+        }
+        if (cur_tile >= ntiles) break;             // frame exhausted: the lanes still asking retire their path below
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ask, 0u));
+        const int avail = 64 - cur_next;
+        if (want_pixel && rank < avail) {
+          const int l = cur_next + rank;
+          const int col = cur_tile / P.gy, by = cur_tile - col * P.gy;
+          px = (P.stripe_rem + col * P.stripe_mod) * 8 + (l >> 3);
+          py = by * 8 + (l & 7);
+          pcode = cur_tile * 64 + l;
+          frame = cur_frame;
+          psteps = 0;
+          sample = 0;
+          color = mk(0, 0, 0);
+          want_pixel = false;
+        }
+        const int n = __popcll(ask);
+        cur_next += n < avail ? n : avail;
+        ask = __ballot(want_pixel);
+      }
+      if (between && px >= 0) {                    // the next path of this slot: K:1065-1073
+        rng.init(sample_seed(P, px, py, sample, frame));
+        camera_ray(P, px, py, rng, path.rayo, path.raydir);
+        path.atten = splat(1.0f);
+        bounce = 0;
+        has_ray = true;
+      }
+      if (s >= 0) {
+        const int ns = has_ray ? PS_READY : PS_RETIRED;
+        if (s == 0) st0 = ns; else st1 = ns;
+        if (has_ray) {
+          rec[0] = make_float4(path.rayo.x, path.rayo.y, path.rayo.z, path.raydir.x);
+          rec[1] = make_float4(path.raydir.y, path.raydir.z, -1.0f, __int_as_float(-1));
+          rec[2] = make_float4(path.atten.x, path.atten.y, path.atten.z, color.x);
+          rec[3] = make_float4(color.y, color.z, __int_as_float(px), __int_as_float(py));
+          rec[4] = make_float4(__uint_as_float(rng.v0), __uint_as_float(rng.v1), __uint_as_float(rng.v2), __uint_as_float(rng.v3));
+          rec[5] = make_float4(__uint_as_float(rng.v4), __uint_as_float(rng.d), __int_as_float(pcode), __int_as_float((frame & 0xffff) | (bounce << 16)));
+          rec[6] = make_float4(__int_as_float(sample), __uint_as_float(psteps), __uint_as_float(0u), 0.0f);
+          so = path.rayo; sd = path.raydir;
+        }
+      }
+      {
+        asm volatile("" ::: "memory");
+        wo = mk(st[0 * 64], st[1 * 64], st[2 * 64]); wd = mk(st[3 * 64], st[4 * 64], st[5 * 64]);
+        tr.best_t = st[6 * 64]; tr.best_slot = __float_as_int(st[7 * 64]); tr.node = __float_as_int(st[8 * 64]);
+        ws.top = __float_as_uint(st[9 * 64]); ws.sp = __float_as_int(st[10 * 64]); wsteps = __float_as_uint(st[11 * 64]);
+        inv = mk(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+        wr = wide_ray(wo, inv, P.wide_pmax);
+      }
+      continue;                                    // lanes that now have a ray start on it at the top of the loop
+    }
+    if (walking == 0ull) break;                    // nothing walks and nothing can be serviced: every path has retired
+    // ---- one record per walking lane (as in the kernel above): lanes at a leaf wait for company
+    {
+      const bool active = cur >= 0 && tr.node >= 0;
+      const bool at_leaf = active && (tr.node & 1);
+      const unsigned long long leaves = __ballot(at_leaf);
+      const unsigned long long nodes = __ballot(active && !(tr.node & 1));
+      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes == 0ull);
+      n_leafstep += do_leaves; n_nodestep += nodes != 0ull;
+      if (active && (!at_leaf || do_leaves)) {
+        const WideRec r = wide_fetch(walk, tr.node);
+        if (at_leaf) wide_leaf_compute<false>(r, wo, wd, inv, tr, ws, my_stack, c);
+        else wide_node_compute<false>(r, wo, inv, wr, tr, ws, my_stack, c);
+        wsteps++;
+      }
+      for (int u = 1; u < P_UNROLL; u++) {
+        n_nodestep += __ballot(cur >= 0 && tr.node >= 0 && !(tr.node & 1)) != 0ull;
+        if (cur >= 0 && tr.node >= 0 && !(tr.node & 1)) {
+          wide_node_step<false>(walk, wo, inv, wr, tr, ws, my_stack, c);
+          wsteps++;
+        }
+      }
+    }
+  }
+  if (lane == 0) {
+    atomicAdd(&P.counters[8], __builtin_readcyclecounter() - t_begin);
+    atomicAdd(&P.counters[15], __builtin_amdgcn_s_memrealtime() - r_begin);
+    atomicAdd(&P.counters[10], (unsigned long long)n_iter);
+    atomicAdd(&P.counters[11], (unsigned long long)n_phase);
+    atomicAdd(&P.counters[12], (unsigned long long)n_nodestep);
+    atomicAdd(&P.counters[13], (unsigned long long)n_leafstep);
+    atomicAdd(&P.counters[14], (unsigned long long)n_served);
+  }
+}
+
 // Cost feedback for the persistent kernel: per-tile cost = the most node steps any of its pixels
 // took (the critical path of the tile), then tiles sorted by cost, most expensive first.
 __global__ __launch_bounds__(256) void tile_cost_kernel(const unsigned* __restrict__ pixel_cost, unsigned* __restrict__ tile_cost, int ntiles) {
@@ -607,6 +844,9 @@ struct dr_context {
   uint8_t* present = nullptr; size_t present_bytes = 0;
   // multi-GPU gather: two packed copies of this context's stripe (double buffer), sized for the accumulator
   int32_t* packed[2] = {nullptr, nullptr}; size_t packed_elems[2] = {0, 0};
+  float4* paths = nullptr; size_t paths_waves = 0;      // render_paired_kernel: two path records per lane
+  int paired = 0;           // wide walk, long launches: 1 = two paths per lane (render_paired_kernel: measured slower), 0 = the one-path kernel
+  int pair_thresh = 48;     // ... phase once this many lanes have a path to service (32, 48 or 56)
   unsigned long long* counters = nullptr;
   unsigned* tile_counters = nullptr; int tile_cursor = 0; int num_cus = 256;
   // cost feedback (persistent kernel): per-pixel cost of the last frame, per-tile cost, tile order
@@ -756,6 +996,15 @@ void launch_tile(dr_context* c, const RenderParams& P) {
   }
 }
 
+// two path records per lane for `waves` waves (render_paired_kernel); false if the memory is not to be had
+bool ensure_paths(dr_context* c, size_t waves) {
+  if (c->paths && c->paths_waves >= waves) return true;
+  if (c->paths) { (void)hipFree(c->paths); c->paths = nullptr; c->paths_waves = 0; }
+  if (hipMalloc((void**)&c->paths, waves * 64 * 2 * PATH_UNITS * sizeof(float4)) != hipSuccess) { (void)hipGetLastError(); return false; }
+  c->paths_waves = waves;
+  return true;
+}
+
 template <int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL = 1>
 void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pixel_cost) {
   const int* rstart = order ? c->region_start : nullptr;        // identity order: the split travels in P.region_start
@@ -766,6 +1015,14 @@ void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, 
   if (traversal_of(c) == DR_TRAVERSAL_WIDE) {
     // the cooperative drain shortens a launch's tail; with many tiles per wave the tail does not show and the leaner build is faster
     const bool coop = P.coop_steps > 0 && (long long)work < (long long)c->coop_tiles_per_wave * blocks * 4;
+    const bool degenerate = P.max_depth <= 0 || !(P.spp_f > 0.0f);
+    if (c->paired && !c->count && !coop && !degenerate && OCC == 5 && ensure_paths(c, (size_t)blocks * 4)) {
+      // long launch: two paths per lane
+      if (c->pair_thresh <= 32) hipLaunchKernelGGL((render_paired_kernel<5, 32, 8, 2>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost, c->paths);
+      else if (c->pair_thresh >= 56) hipLaunchKernelGGL((render_paired_kernel<5, 56, 8, 2>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost, c->paths);
+      else hipLaunchKernelGGL((render_paired_kernel<5, 48, 8, 2>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost, c->paths);
+      return;
+    }
     if (c->count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, false>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
     else if (coop) hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, true>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
     else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, false>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
@@ -849,6 +1106,8 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "coop_steps") { if (v < 0) goto bad; c->coop_steps = v; }
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
   else if (name == "coop_tiles_per_wave") { if (v < 0) goto bad; c->coop_tiles_per_wave = v; }
+  else if (name == "paired") { c->paired = v != 0; }
+  else if (name == "pair_thresh") { if (v != 32 && v != 48 && v != 56) goto bad; c->pair_thresh = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
@@ -954,7 +1213,7 @@ void dr_context_destroy(dr_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* bufs[] = {c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
+  void* bufs[] = {c->paths, c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1023,6 +1282,8 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_steps") *value = c->coop_steps;
   else if (n == "coop_lanes") *value = c->coop_lanes;
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
+  else if (n == "paired") *value = c->paired;
+  else if (n == "pair_thresh") *value = c->pair_thresh;
   else if (n == "tree_depth") *value = c->tree_depth;
   else if (n == "wide_tree") *value = c->wide_tree;
   else if (n == "wide_depth") *value = c->wide ? c->wide_depth : 0;          // 0: the scene has no wide structure

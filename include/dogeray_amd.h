@@ -165,6 +165,9 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   lanes of its wave together (default 16, 0 = off), in waves with at most "coop_lanes" (8) lanes walking;
  *                   the wide walk uses the kernel build that contains it only for launches with fewer than
  *                   "coop_tiles_per_wave" (64) tiles per wave -- short launches, whose tail shows
+ *   "paired"        wide walk, launches with many tiles per wave: 1 = every lane owns two paths (one walked, one waiting to be
+ *                   shaded or holding the next ray), phase once "pair_thresh" (32, 48, 56) lanes have one to service; measured
+ *                   slower than the default one-path kernel, so 0 by default
  *   "wide_tree"     tree under the wide walk, read at dr_context_upload_scene: 1 (default) binned surface-area
  *                   heuristic over the leaf boxes, 0 the reference's own topology (K:1745-1861) collapsed 4-way
  * The environment variable DOGERAY_OPTIONS="name=value,..." applies the same at context creation. */

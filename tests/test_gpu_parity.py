@@ -306,7 +306,10 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
               {"kernel": 1, "occupancy": 4, "trav_min": 48, "park_min": 8, "feedback": 0}, {"kernel": 1, "batch_frames": 3},
               {"kernel": 1, "trav_min": 32, "park_min": 8, "unroll": 1}, {"kernel": 1, "unroll": 3}, {"kernel": 1, "park_min": 16, "unroll": 2},
               {"kernel": 1, "batch_frames": 1, "coop_steps": 1, "coop_lanes": 64}, {"kernel": 1, "batch_frames": 1, "coop_steps": 0},
-              {"kernel": 1, "batch_frames": 2, "coop_steps": 16, "coop_lanes": 4}]
+              {"kernel": 1, "batch_frames": 2, "coop_steps": 16, "coop_lanes": 4},
+              {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 48},       # two paths per lane
+              {"kernel": 1, "batch_frames": 4, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 32},
+              {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 56}]
     for opts in combos:
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -317,7 +320,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         if base is None:
             base = acc
         assert np.array_equal(acc, base), opts
-    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 16, "coop_lanes": 8}.items():
+    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 16, "coop_lanes": 8, "coop_tiles_per_wave": 64, "paired": 0}.items():
         ctx.set_option(k, v)
     assert ctx.get_option("park_min") == 8 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
     with pytest.raises(dr.DogerayError):
@@ -511,3 +514,24 @@ def test_every_committed_reference_scene_renders_like_the_oracle(dr, orc, ctx, s
         assert stats["rays"] == rc["rays"] and stats["shades"] == rc["S"] and stats["texels"] == rc["T"]
         if mode == 0:
             assert stats["node_visits"] == rc["V"] and stats["prim_tests"] == rc["L"]
+
+
+def test_two_paths_per_lane_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
+    """render_paired_kernel (option "paired", off by default): every material, textures, spheres, spp > 1 with a wide lens,
+    margins -- frames identical to the oracle's."""
+    mb4 = with_settings(os.path.join(synth["dir"], "matball.rts"), str(tmp_path / "mb4.rts"),
+                        "*,0,-2.5,7,0.6,0,-0.5,0,7,50,6,4,0.9,synth_env.ppm,192,128")
+    cases = [(mb4, synth["tex"], 192, 128), (os.path.join(SCENES, "scene.rts"), "", 320, 192), (os.path.join(SCENES, "glass.rts"), "", 200, 120),
+             (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192), (os.path.join(synth["dir"], "city_small.rts"), "", 100, 70)]
+    ctx.set_option("paired", 1)
+    ctx.set_option("coop_tiles_per_wave", 0)
+    try:
+        for thresh in (32, 48, 56):
+            ctx.set_option("pair_thresh", thresh)
+            for path, tex, W, H in cases:
+                g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, 1, 99, mode=2, kernel=1)
+                _assert_frames(g, r, "%s two paths per lane, threshold %d" % (os.path.basename(path), thresh))
+    finally:
+        ctx.set_option("paired", 0)
+        ctx.set_option("coop_tiles_per_wave", 64)
+        ctx.set_option("pair_thresh", 48)
