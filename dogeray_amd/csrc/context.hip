@@ -866,7 +866,8 @@ struct dr_context {
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
   int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural, -1 = all by cost)
-  int coop_steps = 16;      // persistent kernel, drain phase: rays older than this many steps are finished cooperatively (0 = off)
+  int coop_steps = 8;       // persistent kernel, drain phase: rays older than this many steps are finished cooperatively (0 = off)
+  int short_blocks_per_cu = 0;    // short launches (fewer than coop_tiles_per_wave tiles per wave): workgroups per CU, 0 = as many as the kernel allows
   int coop_tiles_per_wave = 64;   // wide walk: launches with fewer tiles per wave than this run the build with the cooperative drain
   int coop_lanes = 8;       // ... in waves with at most this many lanes still walking
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
@@ -921,7 +922,7 @@ inline int hf2i(float f) {
 
 // settings[13] -> per-launch constants.  The camera block is K:1016-1052, evaluated once on the
 // host (it is identical for every pixel) with the reference's float/double promotions.
-int make_params(dr_context* c, const float* st, int W, int H, float background, uint64_t seed, RenderParams& P) {
+int make_params(dr_context* c, const float* st, int W, int H, float background, uint64_t seed, RenderParams& P, int batch_hint = 1) {
   if (!c->walk) { set_error("no scene uploaded"); return DR_ERR_INVALID; }
   if (W <= 0 || H <= 0 || (size_t)W * (size_t)H > (size_t)1 << 28) { set_error("bad frame size"); return DR_ERR_INVALID; }
   const int div = hf2i(st[11]);
@@ -969,6 +970,9 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
     const int tiles = P.ncols * P.gy;
     P.regions = c->xcd_regions ? MAX_REGIONS : 1;
     if (tiles < 64 * MAX_REGIONS) P.regions = 1;                 // tiny frames: one queue
+    // a short launch (few tiles per wave: one frame, or a thin stripe of a few) ends when its slowest band ends; one queue
+    // balances better there than eight (1.88 instead of 2.00 ms for a single 1920x1080 frame of the bench scene)
+    if ((long long)tiles * batch_hint < (long long)c->coop_tiles_per_wave * c->num_cus * 20) P.regions = 1;
     for (int r = 0; r <= MAX_REGIONS; r++) P.region_start[r] = r <= P.regions ? (int)(((long long)tiles * r + P.regions - 1) / P.regions) : tiles;
   }
   return DR_OK;
@@ -1010,6 +1014,9 @@ void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, 
   const int* rstart = order ? c->region_start : nullptr;        // identity order: the split travels in P.region_start
   int work = P.ncols * P.gy * P.batch;
   int blocks = c->num_cus * OCC;                   // OCC waves per SIMD on every CU
+  // a short launch lasts as long as its slowest pixel's chain of dependent steps; with fewer waves per SIMD every wave, that
+  // pixel's too, gets a larger share of the issue slots
+  if (c->short_blocks_per_cu > 0 && c->short_blocks_per_cu < OCC && (long long)work < (long long)c->coop_tiles_per_wave * blocks * 4) blocks = c->num_cus * c->short_blocks_per_cu;
   if (blocks * 4 > work) blocks = (work + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
   if (traversal_of(c) == DR_TRAVERSAL_WIDE) {
@@ -1107,6 +1114,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
   else if (name == "coop_tiles_per_wave") { if (v < 0) goto bad; c->coop_tiles_per_wave = v; }
   else if (name == "paired") { c->paired = v != 0; }
+  else if (name == "short_blocks_per_cu") { if (v < 0 || v > 8) goto bad; c->short_blocks_per_cu = v; }
   else if (name == "pair_thresh") { if (v != 32 && v != 48 && v != 56) goto bad; c->pair_thresh = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
@@ -1283,6 +1291,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_lanes") *value = c->coop_lanes;
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
   else if (n == "paired") *value = c->paired;
+  else if (n == "short_blocks_per_cu") *value = c->short_blocks_per_cu;
   else if (n == "pair_thresh") *value = c->pair_thresh;
   else if (n == "tree_depth") *value = c->tree_depth;
   else if (n == "wide_tree") *value = c->wide_tree;
@@ -1350,7 +1359,8 @@ int accumulate_enqueue(dr_context* c, const float settings13[13], int W, int H, 
   if (!c->accum || c->accW != W || c->accH != H) { set_error("call dr_accum_reset(W, H) first"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
   RenderParams P;
-  int rc = make_params(c, settings13, W, H, background, frame_seed, P);
+  const int per = (uses_persistent(c) && c->batch_frames > 1) ? c->batch_frames : 1;
+  int rc = make_params(c, settings13, W, H, background, frame_seed, P, nframes < per ? nframes : per);
   if (rc != DR_OK) return rc;
   if (c->traversal == DR_TRAVERSAL_ORDERED && c->tree_depth > ORDERED_STACK) { set_error("tree too deep for ordered traversal"); return DR_ERR_SCENE; }
   P.out = c->accum;

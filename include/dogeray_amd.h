@@ -162,7 +162,7 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   first), all others keep their natural order (default 1: the above-average tiles; 0: no tile is
  *                   reordered, -1: every tile by cost)
  *   "coop_steps"    once the tile queue is empty, a ray older than this many node steps is finished by all 64
- *                   lanes of its wave together (default 16, 0 = off), in waves with at most "coop_lanes" (8) lanes walking;
+ *                   lanes of its wave together (default 8, 0 = off), in waves with at most "coop_lanes" (8) lanes walking;
  *                   the wide walk uses the kernel build that contains it only for launches with fewer than
  *                   "coop_tiles_per_wave" (64) tiles per wave -- short launches, whose tail shows
  *   "paired"        wide walk, launches with many tiles per wave: 1 = every lane owns two paths (one walked, one waiting to be

@@ -320,7 +320,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         if base is None:
             base = acc
         assert np.array_equal(acc, base), opts
-    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 16, "coop_lanes": 8, "coop_tiles_per_wave": 64, "paired": 0}.items():
+    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 8, "coop_lanes": 8, "coop_tiles_per_wave": 64, "paired": 0}.items():
         ctx.set_option(k, v)
     assert ctx.get_option("park_min") == 8 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
     with pytest.raises(dr.DogerayError):
