@@ -74,10 +74,11 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // next record is a leaf waits until PARK_MIN lanes have one (the leaf step -- exact box + triangle -- is the long
 // block, as the parked triangle test is in the threaded walk); its stack lives in the first WIDE_STACK words of
 // the wave's LDS region, the phase stash behind it.
-// COOP (wide walk): build with the cooperative drain.  It costs registers (96 instead of 80 and a little scratch), so launches
-// whose queue is long enough to hide their tail use the build without it (launch_persistent picks).
+// COOP (wide walk): build with the work-sharing drain (idle lanes take over subtrees of the rays still walking).  It costs registers
+// and LDS (101 VGPRs, 35 KiB per workgroup: four per CU), so launches whose queue is long enough to hide their tail use the build
+// without it (launch_persistent picks).
 template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE, bool COOP = true>
-__global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
+__global__ __launch_bounds__(256, (WIDE && COOP && OCC > 4) ? 4 : OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, const int* __restrict__ region_start,
                                                                      unsigned* __restrict__ pixel_cost) {
   const int lane = threadIdx.x & 63;
@@ -87,11 +88,17 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   //    and while a hit is shaded also the pixel bookkeeping) waits here -- the shading code is where
   //    register pressure peaks, and this keeps the kernel at 96 VGPRs = 5 waves per SIMD;
   //  * outside the phase, the node stack of the cooperative drain (COOP_STACK entries).
-  constexpr int REGION = WIDE ? (WIDE_STACK + WIDE_STASH) * 64 : WAVE_LDS_DWORDS;
-  __shared__ int wave_lds[4 * REGION];
+  // WIDE && COOP: three more words per lane behind the stash -- the shared best hit (64-bit key) and the number of helper lanes of
+  // a ray whose subtrees have been handed out (drain phase, below)
+  constexpr int SHARE_OFF = (WIDE_STACK + WIDE_STASH) * 64;
+  constexpr int REGION = WIDE ? (WIDE_STACK + WIDE_STASH + (COOP ? 4 : 0)) * 64 : WAVE_LDS_DWORDS;
+  __shared__ __attribute__((aligned(16))) int wave_lds[4 * REGION];
   int* const my_lds = wave_lds + (threadIdx.x >> 6) * REGION;
   int* const my_stack = my_lds + lane;                             // WIDE: word k of this lane's stack at my_stack[k * 64]
-  WideStack ws; ws.top = 0u; ws.sp = 0;
+  unsigned long long* const share_key = reinterpret_cast<unsigned long long*>(my_lds + (WIDE ? SHARE_OFF : 0));     // [64], WIDE && COOP only
+  unsigned* const share_pend = reinterpret_cast<unsigned*>(my_lds + (WIDE ? SHARE_OFF : 0) + 128);                   // [64]
+  int share = -1;                  // -1: this lane walks a ray of its own, alone; 0..63: it helps that lane's ray; 64: its ray has helpers
+  WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
   const int ntiles = P.ncols * P.gy;
   const int nwork = ntiles * P.batch;          // queue length: every tile of every frame of the batch
   const WalkRsrc walk = WIDE ? wide_rsrc(P) : walk_rsrc(P);
@@ -135,10 +142,26 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   for (;;) {
     const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;
-    if (__popcll(walking) < TRAV_MIN) {
+    // (a wave that only drains -- queue empty, nobody waiting to be shaded or refilled -- skips the phase: its stash/restore would be
+    // paid on every iteration of the launch's tail)
+    if (WIDE && COOP) {
+      // a helper whose subtree is done reports (its best is in the key already) and is idle again; an owner whose own part is
+      // done takes the shared result once its last helper has reported
+      if (tr.node == -1 && share >= 0 && share < 64) { atomicMin(&share_key[share], hit_key(tr.best_t, tr.best_slot)); atomicSub(&share_pend[share], 1u); tr.node = -3; share = -1; }
+      if (tr.node == -1 && share == 64) {
+        atomicMin(&share_key[lane], hit_key(tr.best_t, tr.best_slot));      // its own last improvement may be newer than the key
+        if (share_pend[lane] == 0u) {
+          const unsigned long long k = share_key[lane];
+          tr.best_t = __uint_as_float((unsigned)(k >> 32)); tr.best_slot = (int)(unsigned)k;
+          share = -1;
+        }
+      }
+    }
+    const bool waits_for_helpers = WIDE && COOP && share == 64;      // (only ever true with tr.node == -1 here or while still walking)
+    if (__popcll(walking) < TRAV_MIN && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers) || tr.node == -2) != 0ull)) {
       unsigned long long t0 = 0;
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
-      const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked);
+      const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked) && !waits_for_helpers;
       if (COUNT) n_shaded += __popcll(__ballot(shade_me));
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
       float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? WIDE_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
@@ -279,7 +302,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         asm volatile("" ::: "memory");
         ws.top = __float_as_uint(st[0 * 64]); ws.sp = __float_as_int(st[1 * 64]);
         inv = mk(st[11 * 64], st[12 * 64], st[13 * 64]);
-        if (fresh_ray) { inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z); ws.top = 0u; ws.sp = 0; }
+        if (fresh_ray) { inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z); ws.top = 0u; ws.sp = 0; ws.sb = 0; }
         wr = wide_ray(path.rayo, inv, P.wide_pmax);            // recomputed for every lane (a dozen instructions) rather than stashed
       } else {
         asm volatile("" ::: "memory");
@@ -292,11 +315,61 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
       if (__ballot(tr.node != -3) == 0ull) break;
     }
-    if (COOP && !COUNT && P.coop_steps > 0 && cur_tile >= ntiles && (int)__popcll(walking) <= P.coop_lanes) {
-      // ---- draining (the queue is empty) and only a few lanes of this wave still walk: a ray that is
-      // already old is finished by the whole wave at once (coop_closest_hit / coop_closest_hit_wide) instead of holding the
-      // launch open for hundreds of further dependent steps.  (The counting build keeps the plain walk so that
-      // its counters stay those of its traversal order.)
+    if (WIDE && COOP && !COUNT && P.coop_steps > 0 && cur_tile >= ntiles) {
+      // ---- draining (the queue is empty): lanes without a pixel take over subtrees of the rays that still walk.  A walking lane
+      // hands the OLDEST word of its stack (the children of a node near the root that it entered but has not visited: the
+      // largest piece of work it owns) to an idle lane, which walks it with the same ray.  All lanes of one ray keep the best
+      // hit in one LDS word (ds_min_u64 on the (t, slot) key: the lexicographic minimum whatever the order) and prune
+      // against it; the owner shades when its own part and every helper's is done.  A ray that would cost one lane hundreds
+      // of dependent steps is spread over the idle lanes at the cost of one hand-over per piece -- every leaf is still
+      // tested by exactly one lane, with the reference's box and arithmetic, against a bound no smaller than the final t.
+      const unsigned long long idle = __ballot(tr.node == -3);
+      const bool can_give = tr.node >= 0 && (ws.sp > ws.sb || ws.top != 0u) && (int)(steps - rstart) >= P.coop_steps;
+      const unsigned long long givers = __ballot(can_give);
+      const int n_idle = (int)__popcll(idle), n_give = (int)__popcll(givers);
+      const int n = n_idle < n_give ? n_idle : n_give;
+      if (n > 0) {
+        int* const xch = my_lds + WIDE_STACK * 64;                 // the phase stash is free between phases: 8 words per hand-over
+        const int rank_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(givers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)givers, 0u));
+        const int rank_i = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+        if (can_give && rank_g < n) {
+          const int root = share >= 0 && share < 64 ? share : lane;               // the lane whose pixel this ray belongs to
+          if (share < 0) { share_key[lane] = hit_key(tr.best_t, tr.best_slot); share_pend[lane] = 0u; share = 64; }
+          atomicAdd(&share_pend[root], 1u);
+          unsigned word;
+          if (ws.sp > ws.sb) { word = (unsigned)my_stack[ws.sb * 64]; ws.sb++; }
+          else { word = ws.top; ws.top = 0u; }
+          xch[rank_g + 0 * 64] = __float_as_int(path.rayo.x); xch[rank_g + 1 * 64] = __float_as_int(path.rayo.y); xch[rank_g + 2 * 64] = __float_as_int(path.rayo.z);
+          xch[rank_g + 3 * 64] = __float_as_int(path.raydir.x); xch[rank_g + 4 * 64] = __float_as_int(path.raydir.y); xch[rank_g + 5 * 64] = __float_as_int(path.raydir.z);
+          xch[rank_g + 6 * 64] = (int)word; xch[rank_g + 7 * 64] = root;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tr.node == -3 && rank_i < n) {
+          path.rayo = mk(__int_as_float(xch[rank_i + 0 * 64]), __int_as_float(xch[rank_i + 1 * 64]), __int_as_float(xch[rank_i + 2 * 64]));
+          path.raydir = mk(__int_as_float(xch[rank_i + 3 * 64]), __int_as_float(xch[rank_i + 4 * 64]), __int_as_float(xch[rank_i + 5 * 64]));
+          ws.top = (unsigned)xch[rank_i + 6 * 64]; ws.sp = 0; ws.sb = 0;
+          share = xch[rank_i + 7 * 64];
+          inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
+          wr = wide_ray(path.rayo, inv, P.wide_pmax);
+          const unsigned long long k = share_key[share];
+          tr.best_t = __uint_as_float((unsigned)(k >> 32)); tr.best_slot = (int)(unsigned)k;
+          wide_pop(tr, ws, my_stack);                              // the first pending child of the word
+          rstart = steps - (unsigned)P.coop_steps;                 // a helper may hand on at once
+        }
+        __builtin_amdgcn_wave_barrier();                           // the exchange words are read before a phase may overwrite them
+      }
+      // lanes of a shared ray: publish an improvement, take over a better bound
+      if (tr.node >= 0 && share >= 0) {
+        const int root = share < 64 ? share : lane;
+        const unsigned long long mine = hit_key(tr.best_t, tr.best_slot), k = share_key[root];
+        if (mine < k) atomicMin(&share_key[root], mine);
+        else if (k < mine) { tr.best_t = __uint_as_float((unsigned)(k >> 32)); tr.best_slot = (int)(unsigned)k; }
+      }
+    }
+    if (!WIDE && COOP && !COUNT && P.coop_steps > 0 && cur_tile >= ntiles && (int)__popcll(walking) <= P.coop_lanes) {
+      // ---- threaded walk, draining: a ray that is already old is finished by the whole wave at once (coop_closest_hit)
       unsigned long long cand = __ballot(tr.node >= 0 && !(PARK_MIN > 0 && pk.parked) && (int)(steps - rstart) >= P.coop_steps);
       while (cand != 0ull) {
         const int L = __ffsll((long long)cand) - 1;
@@ -306,12 +379,9 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         const V3 ud = mk(bcast(path.raydir.x), bcast(path.raydir.y), bcast(path.raydir.z));
         const V3 ui = mk(bcast(inv.x), bcast(inv.y), bcast(inv.z));
         Hit r;
-        bool done;
-        if (WIDE) done = coop_closest_hit_wide(walk, P.wide_pmax, uo, ud, ui, bcast(tr.best_t), __builtin_amdgcn_readlane(tr.best_slot, L),
-                                               my_lds + WIDE_STACK * 64, WIDE_STASH * 64, r);       // the phase stash is free between phases
-        else done = coop_closest_hit(P.pairs, P.prims, uo, ud, ui, bcast(tr.best_t), __builtin_amdgcn_readlane(tr.best_slot, L), my_lds, r);
+        const bool done = coop_closest_hit(P.pairs, P.prims, uo, ud, ui, bcast(tr.best_t), __builtin_amdgcn_readlane(tr.best_slot, L), my_lds, r);
         if (lane == L) {
-          if (done) { tr.best_t = r.t; tr.best_slot = r.slot; tr.node = -1; if (WIDE) { ws.top = 0u; ws.sp = 0; } }
+          if (done) { tr.best_t = r.t; tr.best_slot = r.slot; tr.node = -1; }
           else rstart = 0x80000000u;              // stack overflow: never ask again for this ray ((int)(steps - rstart) is negative from now on)
         }
       }
@@ -427,7 +497,7 @@ __global__ __launch_bounds__(256, OCC) void render_paired_kernel(RenderParams P,
   if (P.regions > 1) region = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % (unsigned)P.regions);   // HW_REG_XCC_ID
   // the walking path: ray, traversal state, steps of this ray
   Trav tr; tr.node = -1; tr.best_t = 0; tr.best_slot = -1;
-  WideStack ws; ws.top = 0u; ws.sp = 0;
+  WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
   V3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), inv = mk(0, 0, 0);
   WideRay wr; wr.inv = wr.marg = mk(0, 0, 0);
   unsigned wsteps = 0;
@@ -866,9 +936,8 @@ struct dr_context {
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
   int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural, -1 = all by cost)
-  int coop_steps = 8;       // persistent kernel, drain phase: rays older than this many steps are finished cooperatively (0 = off)
-  int short_blocks_per_cu = 0;    // short launches (fewer than coop_tiles_per_wave tiles per wave): workgroups per CU, 0 = as many as the kernel allows
-  int coop_tiles_per_wave = 64;   // wide walk: launches with fewer tiles per wave than this run the build with the cooperative drain
+  int coop_steps = 8;       // persistent kernel, drain phase: rays older than this many steps are shared with idle lanes / finished cooperatively (0 = off)
+  int coop_tiles_per_wave = 32;   // wide walk: launches with fewer tiles per wave than this run the build with the work-sharing drain
   int coop_lanes = 8;       // ... in waves with at most this many lanes still walking
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
   float cur_settings[13] = {0};
@@ -1014,14 +1083,12 @@ void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, 
   const int* rstart = order ? c->region_start : nullptr;        // identity order: the split travels in P.region_start
   int work = P.ncols * P.gy * P.batch;
   int blocks = c->num_cus * OCC;                   // OCC waves per SIMD on every CU
-  // a short launch lasts as long as its slowest pixel's chain of dependent steps; with fewer waves per SIMD every wave, that
-  // pixel's too, gets a larger share of the issue slots
-  if (c->short_blocks_per_cu > 0 && c->short_blocks_per_cu < OCC && (long long)work < (long long)c->coop_tiles_per_wave * blocks * 4) blocks = c->num_cus * c->short_blocks_per_cu;
   if (blocks * 4 > work) blocks = (work + 3) / 4;
   dim3 grid((unsigned)blocks), block(256);
   if (traversal_of(c) == DR_TRAVERSAL_WIDE) {
     // the cooperative drain shortens a launch's tail; with many tiles per wave the tail does not show and the leaner build is faster
     const bool coop = P.coop_steps > 0 && (long long)work < (long long)c->coop_tiles_per_wave * blocks * 4;
+    if (coop && !c->count && OCC > 4) grid = dim3((unsigned)(blocks > c->num_cus * 4 ? c->num_cus * 4 : blocks));      // that build's LDS admits four workgroups per CU
     const bool degenerate = P.max_depth <= 0 || !(P.spp_f > 0.0f);
     if (c->paired && !c->count && !coop && !degenerate && OCC == 5 && ensure_paths(c, (size_t)blocks * 4)) {
       // long launch: two paths per lane
@@ -1114,7 +1181,6 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
   else if (name == "coop_tiles_per_wave") { if (v < 0) goto bad; c->coop_tiles_per_wave = v; }
   else if (name == "paired") { c->paired = v != 0; }
-  else if (name == "short_blocks_per_cu") { if (v < 0 || v > 8) goto bad; c->short_blocks_per_cu = v; }
   else if (name == "pair_thresh") { if (v != 32 && v != 48 && v != 56) goto bad; c->pair_thresh = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
@@ -1291,7 +1357,6 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_lanes") *value = c->coop_lanes;
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
   else if (n == "paired") *value = c->paired;
-  else if (n == "short_blocks_per_cu") *value = c->short_blocks_per_cu;
   else if (n == "pair_thresh") *value = c->pair_thresh;
   else if (n == "tree_depth") *value = c->tree_depth;
   else if (n == "wide_tree") *value = c->wide_tree;

@@ -379,7 +379,7 @@ __device__ __forceinline__ bool coop_closest_hit(const DevPair* __restrict__ pai
 // Per lane: `node` = record index << 1 | is-leaf; the children of a node that were entered but not yet visited
 // are one word (first child's index << 8 | leaf mask << 4 | pending mask); the newest such word lives in a
 // register (`top`), older ones on a per-lane stack in LDS (word k of lane l at stack[k * 64 + l]: conflict-free).
-struct WideStack { unsigned top; int sp; };
+struct WideStack { unsigned top; int sp; int sb; };   // LDS words [sb, sp): sb > 0 once the oldest words have been handed to helper lanes
 
 __device__ __forceinline__ float ubyte_f(unsigned w, int k) { return (float)((w >> (8 * k)) & 255u); }   // v_cvt_f32_ubyte<k>
 
@@ -457,10 +457,14 @@ __device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u3
   return mask & (B.w & 15u);
 }
 
+// (t, slot) as one 64-bit key whose unsigned order is the lexicographic order of the pair (t is positive, or the 1e7 of
+// "no hit yet" with slot -1 = the largest unsigned): what lanes that share one ray agree on with ds_min_u64
+__device__ __forceinline__ unsigned long long hit_key(float t, int slot) { return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)slot; }
+
 // next record of this lane: the lowest pending child of the newest stack word, or -1 when nothing is left
 __device__ __forceinline__ void wide_pop(Trav& tr, WideStack& ws, const int* __restrict__ stack) {
   if (ws.top == 0u) {
-    if (ws.sp == 0) { tr.node = -1; return; }
+    if (ws.sp == ws.sb) { tr.node = -1; return; }
     ws.sp--;
     ws.top = (unsigned)stack[ws.sp * 64];
   }
@@ -534,88 +538,11 @@ __device__ __forceinline__ void wide_node_step(WalkRsrc wide, V3 o, V3 inv, cons
   wide_node_compute<COUNT>(r, o, inv, wr, tr, ws, stack, c);
 }
 
-// Cooperative closest hit over the wide walk: all 64 lanes of a wave answer ONE query (the wide-walk counterpart of
-// coop_closest_hit above, used by the persistent kernel while a launch drains: a ray that would cost one lane hundreds
-// of dependent steps is finished in a few dozen rounds).  The wave keeps a stack of record references (index << 1 |
-// is-leaf) in LDS; per round every lane pops one, fetches its record, and either tests the leaf (exact box, primitive)
-// or tests the node's four children against the wave's best t and pushes those that pass.  The result is the
-// lexicographic minimum (t, slot) over every leaf whose own box the ray enters no farther than the best t -- the
-// reference's hit by the same argument as the per-lane walk; the visiting order does not enter it.
-// Returns false (no result) if the stack would overflow; the caller then keeps walking the plain way.
-__device__ __forceinline__ bool coop_closest_hit_wide(WalkRsrc wide, float pmax, V3 o, V3 d, V3 inv, float bound_t, int bound_slot,
-                                                      int* __restrict__ stack, int capacity, Hit& out) {
-  const int lane = (int)__lane_id();
-  const WideRay wr = wide_ray(o, inv, pmax);
-  float best_t = bound_t;
-  unsigned best_slot = (unsigned)bound_slot;            // -1 = none: the largest unsigned
-  float prune_t = bound_t;
-  int n = 1;
-  if (lane == 0) stack[0] = 0;                          // the root node
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  bool ok = true;
-  while (n > 0) {
-    const int take = n < 64 ? n : 64;
-    int ref = -1;
-    if (lane < take) ref = stack[n - 1 - lane];
-    n -= take;
-    unsigned push = 0u, base = 0u, leafmask = 0u;
-    if (ref >= 0) {
-      const WideRec r = wide_fetch(wide, ref);
-      if (ref & 1) {
-        auto f = [](unsigned v) { return __uint_as_float(v); };
-        float mn[3] = {f(r.A.x), f(r.A.y), f(r.A.z)}, mx[3] = {f(r.B.x), f(r.B.y), f(r.B.z)};
-        float dist;
-        if (slab(o, inv, mn, mx, dist) && dist <= prune_t) {
-          const int info = (int)r.A.w;
-          const float t = prim_hit_kind((info >> WALK_SLOT_BITS) & 3, mk(f(r.B.w), f(r.C.x), f(r.C.y)), mk(f(r.C.z), f(r.C.w), f(r.D.x)), mk(f(r.D.y), f(r.D.z), f(r.D.w)), o, d);
-          const unsigned slot = (unsigned)(info & ((1 << WALK_SLOT_BITS) - 1));
-          if (t > 0.0f && (t < best_t || (t == best_t && slot < best_slot))) { best_t = t; best_slot = slot; }
-        }
-      } else {
-        unsigned key;
-        push = wide_node_test(r.A, r.B, r.C, r.D, o, DR_WIDE_FOLD ? wr.inv : inv, wr.marg, prune_t, key);
-        base = r.A.w & 0xffffffu; leafmask = (r.B.w >> 4) & 15u;
-      }
-    }
-    // every lane pushes the children it entered: positions from four ballots
-    int total = 0, pos[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const unsigned long long m = __ballot((push >> k) & 1u);
-      pos[k] = n + total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-      total += __popcll(m);
-    }
-    if (n + total > capacity) { ok = false; break; }
-    __builtin_amdgcn_wave_barrier();            // every lane has read its entry before anyone overwrites it
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-      if ((push >> k) & 1u) stack[pos[k]] = (int)(((base + (unsigned)k) << 1) | ((leafmask >> k) & 1u));
-    n += total;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    prune_t = wave_min_f32(best_t);
-  }
-  if (!ok) return false;
-  for (int off = 32; off > 0; off >>= 1) {      // lexicographic minimum (t, slot) over the lanes
-    const float ot = __shfl_xor(best_t, off, 64);
-    const unsigned os = (unsigned)__shfl_xor((int)best_slot, off, 64);
-    const bool take_other = ot < best_t || (ot == best_t && os < best_slot);
-    best_t = take_other ? ot : best_t;
-    best_slot = take_other ? os : best_slot;
-  }
-  out.t = best_t;
-  out.slot = (int)best_slot;
-  return true;
-}
-
 template <bool COUNT>
 __device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, float pmax, V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [word * 64] */) {
   Trav tr;
   trav_begin(tr);
-  WideStack ws; ws.top = 0u; ws.sp = 0;
+  WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
   const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   const WideRay wr = wide_ray(o, inv, pmax);
   if (COUNT) c.rays++;

@@ -161,10 +161,12 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *   "heavy_factor"  with feedback: tiles that cost more than this many times the mean start first (most expensive
  *                   first), all others keep their natural order (default 1: the above-average tiles; 0: no tile is
  *                   reordered, -1: every tile by cost)
- *   "coop_steps"    once the tile queue is empty, a ray older than this many node steps is finished by all 64
- *                   lanes of its wave together (default 8, 0 = off), in waves with at most "coop_lanes" (8) lanes walking;
- *                   the wide walk uses the kernel build that contains it only for launches with fewer than
- *                   "coop_tiles_per_wave" (64) tiles per wave -- short launches, whose tail shows
+ *   "coop_steps"    drain phase (the tile queue is empty).  Wide walk: a ray older than this many steps (default 8, 0 = off) hands
+ *                   the oldest word of its stack -- a subtree -- to a lane that has no pixel left; all lanes of one ray keep
+ *                   the best hit in one LDS word and the owner shades when every piece is done.  The kernel build that contains
+ *                   this is used for launches with fewer than "coop_tiles_per_wave" (32) tiles per wave: short launches,
+ *                   whose tail shows.  Threaded walk: such a ray is finished by all 64 lanes breadth-first, in waves with at
+ *                   most "coop_lanes" (8) lanes walking
  *   "paired"        wide walk, launches with many tiles per wave: 1 = every lane owns two paths (one walked, one waiting to be
  *                   shaded or holding the next ray), phase once "pair_thresh" (32, 48, 56) lanes have one to service; measured
  *                   slower than the default one-path kernel, so 0 by default

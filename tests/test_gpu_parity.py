@@ -320,7 +320,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         if base is None:
             base = acc
         assert np.array_equal(acc, base), opts
-    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 8, "coop_lanes": 8, "coop_tiles_per_wave": 64, "paired": 0}.items():
+    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 8, "coop_lanes": 8, "coop_tiles_per_wave": 32, "paired": 0}.items():
         ctx.set_option(k, v)
     assert ctx.get_option("park_min") == 8 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
     with pytest.raises(dr.DogerayError):
@@ -533,5 +533,27 @@ def test_two_paths_per_lane_kernel_renders_like_the_oracle(dr, orc, ctx, synth, 
                 _assert_frames(g, r, "%s two paths per lane, threshold %d" % (os.path.basename(path), thresh))
     finally:
         ctx.set_option("paired", 0)
-        ctx.set_option("coop_tiles_per_wave", 64)
+        ctx.set_option("coop_tiles_per_wave", 32)
         ctx.set_option("pair_thresh", 48)
+
+
+def test_work_sharing_drain_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
+    """The drain phase of short launches hands subtrees of the rays still walking to idle lanes (shared best hit by ds_min_u64 on the
+    (t, slot) key).  With coop_steps = 1 every ray that can be shared is: fuzzed scenes (coincident triangles: ties must still go
+    to the lower slot, whichever lane finds them), spheres, textures, spp > 1 -- frames identical to the oracle's."""
+    from scene_fuzz import random_scene
+    rng = np.random.default_rng(123)
+    names = ["synth_albedo.ppm", "synth_rough.ppm", "synth_env.ppm", "a.ppm"]
+    cases = [(random_scene(rng, int(rng.integers(50, 900)), str(tmp_path / ("share%d.rts" % k)), W=96, H=64, textures=names), synth["tex"], 96, 64) for k in range(6)]
+    cases += [(os.path.join(SCENES, "scene.rts"), "", 320, 192), (os.path.join(synth["dir"], "hf_small.rts"), "", 320, 192),
+              (os.path.join(synth["dir"], "city_small.rts"), "", 200, 120)]
+    for steps, lanes in ((1, 64), (4, 8)):
+        ctx.set_option("coop_steps", steps)
+        ctx.set_option("coop_lanes", lanes)
+        try:
+            for path, tex, W, H in cases:
+                g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, 1, 4321, mode=2, kernel=1)
+                _assert_frames(g, r, "%s shared drain, coop_steps %d" % (os.path.basename(path), steps))
+        finally:
+            ctx.set_option("coop_steps", 8)
+            ctx.set_option("coop_lanes", 8)
