@@ -758,11 +758,19 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, flo
     uint32_t px = tex_fetch<COUNT>(P.tex, P.texels, rtexnum, texco.x, -texco.y + 1, c);
     rough = float(px & 255u) / 255 / 2;
   }
-  // ---- scatter K:848-944
-  if (mat == 0) {
+  // ---- scatter K:848-944.  The random draws come first, ONE copy of each loop for every lane that needs it: diffuse (0),
+  // metal (3) and glossy (5) all draw a point in the unit sphere, glossy after its one uniform -- the order of draws
+  // of each lane is the reference's, but a wave runs the rejection loop once instead of once per material branch (the
+  // five copies of that loop were most of the shade phase: 106 VALU instructions per turn, 27 of them f64).
+  float r5 = 0.0f;
+  if (mat == 5) r5 = randy(rng);
+  V3 rs = mk(0, 0, 0);
+  if (mat == 0 || mat == 3 || mat == 5) rs = rand_in_unit_sphere(rng);
+  const bool like_metal = mat == 3 || (mat == 5 && r5 > 0.8);      // float compared with the double 0.8
+  if (mat == 0 || (mat == 5 && !like_metal)) {
     V3 target = hitpoint + N;
-    if (add_x == 0) target = target + rand_in_unit_sphere(rng);
-    else target = target + normalized(rand_in_unit_sphere(rng));
+    if (mat == 5 || add_x == 0) target = target + rs;              // glossy never normalises (K:899)
+    else target = target + normalized(rs);
     atten = atten * ocolor;
     rayo = hitpoint;
     raydir = normalized(target - hitpoint);
@@ -770,25 +778,11 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, flo
     atten = atten * ocolor;
     rayo = hitpoint;
     raydir = reflect(normalized(raydir), N);
-  } else if (mat == 3) {
+  } else if (like_metal) {
     V3 refl = reflect(normalized(raydir), N);
     atten = atten * ocolor;
     rayo = hitpoint;
-    raydir = refl + splat(rough) * rand_in_unit_sphere(rng);
-  } else if (mat == 5) {
-    float r = randy(rng);
-    if (r > 0.8) {                           // float compared with the double 0.8
-      V3 refl = reflect(normalized(raydir), N);
-      atten = atten * ocolor;
-      rayo = hitpoint;
-      raydir = refl + splat(rough) * rand_in_unit_sphere(rng);
-    } else {
-      V3 target = hitpoint + N;
-      target = target + rand_in_unit_sphere(rng);
-      atten = atten * ocolor;
-      rayo = hitpoint;
-      raydir = normalized(target - hitpoint);
-    }
+    raydir = refl + splat(rough) * rs;
   } else if (mat == 4) {
     float ir = s5.z;                         // b[g].addional.y itself, not the textured roughness (K:917)
     float ratio = front ? (1.0f / ir) : ir;
