@@ -402,6 +402,22 @@ __global__ __launch_bounds__(256, (WIDE && COOP && OCC > 4) ? 4 : OCC) void rend
         else wide_node_compute<COUNT>(r, path.rayo, inv, wr, tr, ws, my_stack, c);
         steps++;
       }
+#if DR_MERGED_STEPS
+      for (int u = 1; u < P_UNROLL; u++) {         // the further steps of an iteration take leaf lanes along too
+        const bool at_leaf2 = tr.node >= 0 && (tr.node & 1);
+        const unsigned long long leaves2 = __ballot(at_leaf2);
+        const unsigned long long nodes2 = __ballot(tr.node >= 0 && !(tr.node & 1));
+        const bool do_leaves2 = leaves2 != 0ull && ((int)__popcll(leaves2) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes2 == 0ull || cur_tile >= ntiles);
+        if (COUNT) { n_leafstep += do_leaves2; n_nodestep += nodes2 != 0ull; }
+        if (tr.node >= 0 && (!at_leaf2 || do_leaves2)) {
+          if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
+          const WideRec r = wide_fetch(walk, tr.node);
+          if (at_leaf2) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, tr, ws, my_stack, c);
+          else wide_node_compute<COUNT>(r, path.rayo, inv, wr, tr, ws, my_stack, c);
+          steps++;
+        }
+      }
+#else
       for (int u = 1; u < P_UNROLL; u++) {
         if (COUNT) n_nodestep += __ballot(tr.node >= 0 && !(tr.node & 1)) != 0ull;
         if (tr.node >= 0 && !(tr.node & 1)) {
@@ -410,6 +426,7 @@ __global__ __launch_bounds__(256, (WIDE && COOP && OCC > 4) ? 4 : OCC) void rend
           steps++;
         }
       }
+#endif
     } else if (PARK_MIN > 0) {
       // ---- test the parked leaves once enough lanes hold one (or nobody could step anyway)
       const unsigned long long parked = __ballot(pk.parked);
@@ -695,6 +712,337 @@ __global__ __launch_bounds__(256, OCC) void render_paired_kernel(RenderParams P,
   }
 }
 
+// Waves with roles (wide walk, long launches; option "roles").
+//
+// In the kernels above node steps, leaf steps and shading share a wave, and each runs for a fraction of its lanes (26 / 25 / 34
+// of 64 on the bench scene).  Here a workgroup is NT trace waves and one shade wave that exchange work through rings in LDS:
+//   ray ring   (one, written by the shade wave)        {path, origin, direction}: a trace lane that has finished takes the next ray
+//   hit rings  (one per trace wave, read by the shade wave)   {path, t, slot}
+// A trace wave is the node / leaf loop and nothing else; a lane refills the moment its walk ends, so the loop stays full.  The
+// shade wave takes 64 hits at a time from the rings, loads each path's state (global memory, touched by this wave only),
+// shades at full width, and puts the next ray -- or the camera ray of the next sample or pixel, tiles from the same per-XCD
+// queues -- into the ray ring.  A workgroup owns RK_PATHS paths; the ray ring holds as many entries, so it never fills, and a
+// trace wave waits when its hit ring is full (the shade wave always drains it).  Counters only grow (unsigned differences);
+// a ring entry is written before the counter that publishes it (LDS operations of one wave execute in order).  Every
+// wait is bounded: a wave that spins too long raises the workgroup's abort flag and everybody leaves (the frame is then
+// incomplete: the host checks the flag and fails the call).  The arithmetic of a path is the same functions in the same
+// order; which wave carries which part does not enter it.
+constexpr unsigned RK_SPIN_LIMIT = 1u << 22;
+
+// NT trace waves + NS shade waves per workgroup ((NT + NS) a multiple of 4).  A path belongs to ONE shade wave (its state is never
+// touched by another wave): shade wave s owns paths [s * RS, (s + 1) * RS) of the workgroup, has its own ray ring of RS entries
+// (never full) and reads the hit rings [trace wave][s]; a trace lane takes rays from either ray ring and returns the hit to
+// the ring of the path's owner.
+template <int NT, int NS, int PARK_MIN, int P_UNROLL>
+__global__ __launch_bounds__((NT + NS) * 64, 4) void render_roles_kernel(RenderParams P, unsigned* tile_counter, const int* __restrict__ tile_order,
+                                                                         const int* __restrict__ region_start, float4* __restrict__ paths,
+                                                                         unsigned* __restrict__ abort_flag) {
+  constexpr int RS = 512;                 // paths (= ray ring entries) per shade wave
+  constexpr int HQ = NS == 1 ? 128 : 64;  // entries per hit ring
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  __shared__ int stacks[NT * WIDE_STACK * 64];
+  __shared__ int ray_pid[NS][RS];
+  __shared__ float ray_o[NS][3][RS], ray_d[NS][3][RS];
+  __shared__ int hit_pid[NT][NS][HQ];
+  __shared__ float hit_t[NT][NS][HQ];
+  __shared__ int hit_slot[NT][NS][HQ];
+  __shared__ unsigned ray_published[NS], ray_claimed[NS], hit_tail[NT][NS], hit_head[NT][NS], done_flag[NS], abort_lds;
+  if (threadIdx.x == 0) abort_lds = 0u;
+  if (threadIdx.x < NS) { ray_published[threadIdx.x] = 0u; ray_claimed[threadIdx.x] = 0u; done_flag[threadIdx.x] = 0u; }
+  if (threadIdx.x < NT * NS) { (&hit_tail[0][0])[threadIdx.x] = 0u; (&hit_head[0][0])[threadIdx.x] = 0u; }
+  __syncthreads();
+  const unsigned long long t_begin = __builtin_readcyclecounter(), r_begin = __builtin_amdgcn_s_memrealtime();
+  Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned n_iter = 0, n_nodestep = 0, n_leafstep = 0, n_phase = 0, n_served = 0;
+  auto give_up = [&]() { if (lane == 0) { *(volatile unsigned*)&abort_lds = 1u; atomicExch(abort_flag, 1u); } };
+
+  if (wave < NT) {
+    // ================================================================ trace wave
+    const WalkRsrc walk = wide_rsrc(P);
+    int* const my_stack = stacks + wave * (WIDE_STACK * 64) + lane;
+    Trav tr; tr.node = -1; tr.best_t = 0; tr.best_slot = -1;
+    WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
+    V3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), inv = mk(0, 0, 0);
+    WideRay wr; wr.inv = wr.marg = mk(0, 0, 0);
+    int pid = -1;                       // the path this lane walks for (index within the workgroup), -1 none
+    unsigned my_tail[NS];               // this wave's hit rings: entries written so far (wave-uniform)
+#pragma unroll
+    for (int q = 0; q < NS; q++) my_tail[q] = 0u;
+    unsigned spins = 0u;
+    bool leave = false;
+    for (;;) {
+      n_iter++;
+      // ---- finished walks go to the hit ring of the path's shade wave
+#pragma unroll
+      for (int q = 0; q < NS; q++) {
+        const bool mine = pid >= 0 && tr.node == -1 && (NS == 1 || pid / RS == q);
+        const unsigned long long fin = __ballot(mine);
+        if (fin == 0ull) continue;
+        const unsigned n = (unsigned)__popcll(fin);
+        unsigned head = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)&hit_head[wave][q]);
+        while (my_tail[q] - head + n > (unsigned)HQ) {            // the shade wave drains the ring; wave-uniform wait
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > RK_SPIN_LIMIT) give_up();
+          if (*(volatile unsigned*)&abort_lds) { leave = true; break; }
+          head = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)&hit_head[wave][q]);
+        }
+        if (leave) break;
+        if (mine) {
+          const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(fin >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)fin, 0u));
+          const unsigned e = (my_tail[q] + rank) & (HQ - 1);
+          hit_t[wave][q][e] = tr.best_slot < 0 ? -1.0f : tr.best_t;
+          hit_slot[wave][q][e] = tr.best_slot;
+          hit_pid[wave][q][e] = pid;
+          pid = -1;
+        }
+        my_tail[q] += n;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) *(volatile unsigned*)&hit_tail[wave][q] = my_tail[q];       // published after the entries
+      }
+      if (leave) break;
+      // ---- lanes without a ray take the next ones of the ray rings
+#pragma unroll
+      for (int k = 0; k < NS; k++) {
+        const int q = NS == 1 ? 0 : (k ^ (int)((n_iter + (unsigned)wave) & 1u));   // alternate which ring is asked first
+        const unsigned long long idle = __ballot(pid < 0);
+        if (idle == 0ull) break;
+        unsigned base = 0u, m = 0u;
+        if (lane == 0) {
+          const unsigned want = (unsigned)__popcll(idle);
+          for (int tries = 0; tries < 64; tries++) {
+            const unsigned cl = *(volatile unsigned*)&ray_claimed[q], pub = *(volatile unsigned*)&ray_published[q];
+            const unsigned avail = pub - cl;
+            if (avail == 0u) break;
+            const unsigned take = want < avail ? want : avail;
+            if (atomicCAS(&ray_claimed[q], cl, cl + take) == cl) { base = cl; m = take; break; }
+          }
+        }
+        base = __builtin_amdgcn_readfirstlane(base); m = __builtin_amdgcn_readfirstlane(m);
+        if (m > 0u) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+          if (pid < 0 && rank < m) {
+            const unsigned e = (base + rank) & (RS - 1);
+            pid = ray_pid[q][e];
+            wo = mk(ray_o[q][0][e], ray_o[q][1][e], ray_o[q][2][e]); wd = mk(ray_d[q][0][e], ray_d[q][1][e], ray_d[q][2][e]);
+            inv = mk(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+            wr = wide_ray(wo, inv, P.wide_pmax);
+            trav_begin(tr);
+            ws.top = 0u; ws.sp = 0; ws.sb = 0;
+          }
+        }
+      }
+      const unsigned long long walking = __ballot(pid >= 0 && tr.node >= 0);
+      if (walking == 0ull) {
+        bool all_done = true;
+#pragma unroll
+        for (int q = 0; q < NS; q++) all_done = all_done && *(volatile unsigned*)&done_flag[q] != 0u;
+        if (all_done || *(volatile unsigned*)&abort_lds) break;
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > RK_SPIN_LIMIT) { give_up(); break; }
+        continue;
+      }
+      spins = 0u;
+      // ---- one record per walking lane; lanes at a leaf wait for company (as in render_persistent_kernel)
+      {
+        const bool active = pid >= 0 && tr.node >= 0;
+        const bool at_leaf = active && (tr.node & 1);
+        const unsigned long long leaves = __ballot(at_leaf);
+        const unsigned long long nodes = __ballot(active && !(tr.node & 1));
+        const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes == 0ull);
+        n_leafstep += do_leaves; n_nodestep += nodes != 0ull;
+        if (active && (!at_leaf || do_leaves)) {
+          const WideRec r = wide_fetch(walk, tr.node);
+          if (at_leaf) wide_leaf_compute<false>(r, wo, wd, inv, tr, ws, my_stack, c);
+          else wide_node_compute<false>(r, wo, inv, wr, tr, ws, my_stack, c);
+        }
+        for (int u = 1; u < P_UNROLL; u++) {
+          n_nodestep += __ballot(pid >= 0 && tr.node >= 0 && !(tr.node & 1)) != 0ull;
+          if (pid >= 0 && tr.node >= 0 && !(tr.node & 1)) wide_node_step<false>(walk, wo, inv, wr, tr, ws, my_stack, c);
+        }
+      }
+    }
+  } else {
+    // ================================================================ shade wave
+    const int sq = wave - NT;            // which shade wave: owns paths [sq * RS, (sq + 1) * RS) and ray ring sq
+    const int ntiles = P.ncols * P.gy;
+    int cur_tile = ntiles, cur_frame = 0, cur_next = 64;
+    int region = 0, regions_left = P.regions;
+    if (P.regions > 1) region = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % (unsigned)P.regions);   // HW_REG_XCC_ID
+    float4* const my_paths = paths + ((size_t)blockIdx.x * NS + (size_t)sq) * RS * PATH_UNITS;
+    unsigned my_head[NT];
+#pragma unroll
+    for (int w = 0; w < NT; w++) my_head[w] = 0u;
+    unsigned pub = 0u;                  // rays published so far
+    int retired = 0, started = 0;       // paths of this wave that have ended for good / that have been given their first pixel
+    unsigned spins = 0u;
+    for (;;) {
+      n_iter++;
+      // ---- up to 64 hits from the rings, or (first) paths that have never had a pixel
+      int hpid = -1; float hit_tv = -1.0f; int hit_sv = -1;
+      bool fresh = false;               // a path that starts: no hit to shade
+      if (started < RS) {
+        hpid = started + lane;
+        fresh = hpid < RS;
+        if (!fresh) hpid = -1;
+        started += 64;
+      } else {
+        int taken = 0;
+#pragma unroll
+        for (int w = 0; w < NT; w++) {
+          const unsigned tail = __builtin_amdgcn_readfirstlane(*(volatile unsigned*)&hit_tail[w][sq]);
+          const int avail = (int)(tail - my_head[w]);
+          const int take = avail < 64 - taken ? avail : 64 - taken;
+          if (take > 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if (lane >= taken && lane < taken + take) {
+              const unsigned e = (my_head[w] + (unsigned)(lane - taken)) & (HQ - 1);
+              hpid = hit_pid[w][sq][e] - sq * RS; hit_tv = hit_t[w][sq][e]; hit_sv = hit_slot[w][sq][e];
+            }
+            my_head[w] += (unsigned)take;
+            taken += take;
+          }
+        }
+        if (taken > 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // the entries are read before their slots are handed back
+#pragma unroll
+          for (int w = 0; w < NT; w++) if (lane == w) *(volatile unsigned*)&hit_head[w][sq] = my_head[w];
+        }
+      }
+      const unsigned long long have = __ballot(hpid >= 0);
+      if (have == 0ull) {
+        if (retired >= RS) { if (lane == 0) *(volatile unsigned*)&done_flag[sq] = 1u; break; }
+        if (*(volatile unsigned*)&abort_lds) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++spins > RK_SPIN_LIMIT) { give_up(); break; }
+        continue;
+      }
+      spins = 0u;
+      n_phase++; n_served += (unsigned)__popcll(have);
+      float4* const rec = my_paths + (size_t)(hpid < 0 ? 0 : hpid) * PATH_UNITS;
+      Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
+      V3 color = mk(0, 0, 0);
+      Xorwow rng; rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = rng.d = 0;
+      int px = -1, py = 0, frame = 0, bounce = 0, sample = 0;
+      const bool shade_me = hpid >= 0 && !fresh;
+      if (shade_me) {
+        const float4 u0 = rec[0], u1 = rec[1], u2 = rec[2], u3 = rec[3], u4 = rec[4], u5 = rec[5], u6 = rec[6];
+        path.rayo = mk(u0.x, u0.y, u0.z); path.raydir = mk(u0.w, u1.x, u1.y);
+        path.atten = mk(u2.x, u2.y, u2.z); color = mk(u2.w, u3.x, u3.y);
+        px = __float_as_int(u3.z); py = __float_as_int(u3.w);
+        rng.v0 = __float_as_uint(u4.x); rng.v1 = __float_as_uint(u4.y); rng.v2 = __float_as_uint(u4.z); rng.v3 = __float_as_uint(u4.w);
+        rng.v4 = __float_as_uint(u5.x); rng.d = __float_as_uint(u5.y);
+        frame = __float_as_int(u5.w) & 0xffff; bounce = __float_as_int(u5.w) >> 16;
+        sample = __float_as_int(u6.x);
+      }
+      bool between = fresh;
+      bool has_ray = false;
+      if (shade_me) {
+        bool ended;
+        V3 radiance = mk(0, 0, 0);
+        if (hit_sv >= 0 && hit_tv > 0.0f) {
+          ended = !shade_hit<false>(P, path, hit_tv, hit_sv, rng, c, radiance);
+          if (!ended) { bounce++; if (bounce >= P.max_depth) ended = true; }        // depth exhausted: black (K:981)
+        } else {
+          radiance = shade_miss<false>(P, path, c);
+          ended = true;
+        }
+        if (ended) { color = color + radiance; sample++; between = true; }
+        else has_ray = true;
+      }
+      bool want_pixel = false;
+      if (between) {
+        if (px >= 0 && (float)sample < P.spp_f) {
+          // same pixel, next sample (K:1059)
+        } else {
+          if (px >= 0) store_pixel(P, px, py, color);
+          px = -1;
+          want_pixel = true;
+        }
+      }
+      unsigned long long ask = __ballot(want_pixel);
+      while (ask != 0ull) {
+        if (cur_next >= 64) {                      // wave-uniform: fetch the next chunk (tile, frame)
+          cur_tile = ntiles;
+          while (regions_left > 0) {
+            const int r0 = region_start ? region_start[region] : P.region_start[region];
+            const int r1 = region_start ? region_start[region + 1] : P.region_start[region + 1];
+            unsigned t = 0;
+            if (lane == 0) t = atomicAdd(tile_counter + region, 1u);
+            const int q = (int)__builtin_amdgcn_readfirstlane(t);
+            if (q < (r1 - r0) * P.batch) {
+              const int tt = q / P.batch;
+              cur_frame = q - tt * P.batch;
+              cur_tile = tile_order ? tile_order[r0 + tt] : r0 + tt;
+              break;
+            }
+            region = region + 1 == P.regions ? 0 : region + 1;   // this band is done: help with the next one
+            regions_left--;
+          }
+          cur_next = 0;
+        }
+        if (cur_tile >= ntiles) break;             // frame exhausted: the paths still asking retire below
+        const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(ask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ask, 0u));
+        const int avail = 64 - cur_next;
+        if (want_pixel && rank < avail) {
+          const int l = cur_next + rank;
+          const int col = cur_tile / P.gy, by = cur_tile - col * P.gy;
+          px = (P.stripe_rem + col * P.stripe_mod) * 8 + (l >> 3);
+          py = by * 8 + (l & 7);
+          frame = cur_frame;
+          sample = 0;
+          color = mk(0, 0, 0);
+          want_pixel = false;
+        }
+        const int n = __popcll(ask);
+        cur_next += n < avail ? n : avail;
+        ask = __ballot(want_pixel);
+      }
+      if (between && px >= 0) {                    // the next path of this slot: K:1065-1073
+        rng.init(sample_seed(P, px, py, sample, frame));
+        camera_ray(P, px, py, rng, path.rayo, path.raydir);
+        path.atten = splat(1.0f);
+        bounce = 0;
+        has_ray = true;
+      }
+      retired += (int)__popcll(__ballot(hpid >= 0 && !has_ray));
+      // ---- state back to memory, rays into the ring
+      if (has_ray) {
+        rec[0] = make_float4(path.rayo.x, path.rayo.y, path.rayo.z, path.raydir.x);
+        rec[1] = make_float4(path.raydir.y, path.raydir.z, 0.0f, 0.0f);
+        rec[2] = make_float4(path.atten.x, path.atten.y, path.atten.z, color.x);
+        rec[3] = make_float4(color.y, color.z, __int_as_float(px), __int_as_float(py));
+        rec[4] = make_float4(__uint_as_float(rng.v0), __uint_as_float(rng.v1), __uint_as_float(rng.v2), __uint_as_float(rng.v3));
+        rec[5] = make_float4(__uint_as_float(rng.v4), __uint_as_float(rng.d), 0.0f, __int_as_float((frame & 0xffff) | (bounce << 16)));
+        rec[6] = make_float4(__int_as_float(sample), 0.0f, 0.0f, 0.0f);
+      }
+      const unsigned long long push = __ballot(has_ray);
+      if (push != 0ull) {
+        if (has_ray) {
+          const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(push >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)push, 0u));
+          const unsigned e = (pub + rank) & (RS - 1);
+          ray_pid[sq][e] = hpid + sq * RS;
+          ray_o[sq][0][e] = path.rayo.x; ray_o[sq][1][e] = path.rayo.y; ray_o[sq][2][e] = path.rayo.z;
+          ray_d[sq][0][e] = path.raydir.x; ray_d[sq][1][e] = path.raydir.y; ray_d[sq][2][e] = path.raydir.z;
+        }
+        pub += (unsigned)__popcll(push);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) *(volatile unsigned*)&ray_published[sq] = pub;
+      }
+    }
+  }
+  if (lane == 0) {
+    atomicAdd(&P.counters[8], __builtin_readcyclecounter() - t_begin);
+    atomicAdd(&P.counters[15], __builtin_amdgcn_s_memrealtime() - r_begin);
+    atomicAdd(&P.counters[10], (unsigned long long)n_iter);
+    atomicAdd(&P.counters[11], (unsigned long long)n_phase);
+    atomicAdd(&P.counters[12], (unsigned long long)n_nodestep);
+    atomicAdd(&P.counters[13], (unsigned long long)n_leafstep);
+    atomicAdd(&P.counters[14], (unsigned long long)n_served);
+  }
+}
+
 // Cost feedback for the persistent kernel: per-tile cost = the most node steps any of its pixels
 // took (the critical path of the tile), then tiles sorted by cost, most expensive first.
 __global__ __launch_bounds__(256) void tile_cost_kernel(const unsigned* __restrict__ pixel_cost, unsigned* __restrict__ tile_cost, int ntiles) {
@@ -915,6 +1263,9 @@ struct dr_context {
   // multi-GPU gather: two packed copies of this context's stripe (double buffer), sized for the accumulator
   int32_t* packed[2] = {nullptr, nullptr}; size_t packed_elems[2] = {0, 0};
   float4* paths = nullptr; size_t paths_waves = 0;      // render_paired_kernel: two path records per lane
+  unsigned* abort_flag = nullptr;                        // render_roles_kernel: set by a wave that waited too long (protocol failure)
+  bool roles_used = false;
+  int roles = 0;            // wide walk, long launches: 3 / 7 = workgroups of that many trace waves + one shade wave, 6 = 6 + 2 (render_roles_kernel)
   int paired = 0;           // wide walk, long launches: 1 = two paths per lane (render_paired_kernel: measured slower), 0 = the one-path kernel
   int pair_thresh = 48;     // ... phase once this many lanes have a path to service (32, 48 or 56)
   unsigned long long* counters = nullptr;
@@ -932,7 +1283,7 @@ struct dr_context {
   int kernel = DR_KERNEL_PERSISTENT;
   int occupancy = 5;        // waves per SIMD the kernel is built and launched for (persistent: 4 or 5; tile kernel: 4 or 6)
   int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
-  int park_min = 8;         // persistent kernel: test parked leaves once this many lanes hold one (0 = test on the spot)
+  int park_min = 16;        // persistent kernel: leaf steps (parked leaves) once this many lanes stand at one (0 = on the spot)
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
   int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural, -1 = all by cost)
@@ -1070,11 +1421,26 @@ void launch_tile(dr_context* c, const RenderParams& P) {
 }
 
 // two path records per lane for `waves` waves (render_paired_kernel); false if the memory is not to be had
-bool ensure_paths(dr_context* c, size_t waves) {
+bool ensure_paths(dr_context* c, size_t waves) {       // `waves` x 128 path records
   if (c->paths && c->paths_waves >= waves) return true;
   if (c->paths) { (void)hipFree(c->paths); c->paths = nullptr; c->paths_waves = 0; }
   if (hipMalloc((void**)&c->paths, waves * 64 * 2 * PATH_UNITS * sizeof(float4)) != hipSuccess) { (void)hipGetLastError(); return false; }
   c->paths_waves = waves;
+  return true;
+}
+
+// workgroups of trace waves + a shade wave; false if it cannot run (then the caller launches the one-path kernel)
+template <int NT, int NS>
+bool launch_roles(dr_context* c, const RenderParams& P, unsigned* counter) {
+  const int blocks = c->num_cus * 16 / (NT + NS);       // 16 waves per CU
+  if (!ensure_paths(c, (size_t)blocks * NS * 512 / 128)) return false;
+  if (!c->abort_flag) {
+    if (hipMalloc((void**)&c->abort_flag, sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); c->abort_flag = nullptr; return false; }
+    (void)hipMemsetAsync(c->abort_flag, 0, sizeof(unsigned), c->stream);
+  }
+  hipLaunchKernelGGL((render_roles_kernel<NT, NS, 8, 2>), dim3((unsigned)blocks), dim3((NT + NS) * 64), 0, c->stream, P, counter, (const int*)nullptr, (const int*)nullptr,
+                     c->paths, c->abort_flag);
+  c->roles_used = true;
   return true;
 }
 
@@ -1156,6 +1522,8 @@ void enqueue_frame(dr_context* c, const RenderParams& P) {
     }
     unsigned* counter = c->tile_counters + c->tile_cursor;      // one counter per region
     c->tile_cursor += MAX_REGIONS;
+    if (c->roles && traversal_of(c) == DR_TRAVERSAL_WIDE && !c->count && P.max_depth > 0 && P.spp_f > 0.0f &&
+        (long long)tiles * P.batch >= (long long)c->coop_tiles_per_wave * c->num_cus * 20 && (c->roles == 7 ? launch_roles<7, 1>(c, P, counter) : (c->roles == 6 ? launch_roles<6, 2>(c, P, counter) : launch_roles<3, 1>(c, P, counter)))) return;
     const int* order; unsigned* pcost;
     feedback_buffers(c, P, tiles, order, pcost);
     if (c->occupancy >= 5) launch_persistent_occ<5>(c, P, counter, order, pcost);
@@ -1181,6 +1549,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
   else if (name == "coop_tiles_per_wave") { if (v < 0) goto bad; c->coop_tiles_per_wave = v; }
   else if (name == "paired") { c->paired = v != 0; }
+  else if (name == "roles") { if (v != 0 && v != 3 && v != 6 && v != 7) goto bad; c->roles = v; }
   else if (name == "pair_thresh") { if (v != 32 && v != 48 && v != 56) goto bad; c->pair_thresh = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
@@ -1201,6 +1570,16 @@ int launch_render(dr_context* c, const RenderParams& P) {
   enqueue_frame(c, P);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
+  return DR_OK;
+}
+
+int check_abort(dr_context* c) {
+  if (!c->roles_used) return DR_OK;
+  unsigned f = 0;
+  HIP_TRY(hipMemcpyAsync(&f, c->abort_flag, sizeof(f), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  c->roles_used = false;
+  if (f) { (void)hipMemsetAsync(c->abort_flag, 0, sizeof(unsigned), c->stream); set_error("render_roles_kernel gave up waiting (internal protocol failure): the frame is incomplete"); return DR_ERR_DEVICE; }
   return DR_OK;
 }
 
@@ -1287,7 +1666,7 @@ void dr_context_destroy(dr_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* bufs[] = {c->paths, c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
+  void* bufs[] = {c->abort_flag, c->paths, c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1357,6 +1736,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_lanes") *value = c->coop_lanes;
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
   else if (n == "paired") *value = c->paired;
+  else if (n == "roles") *value = c->roles;
   else if (n == "pair_thresh") *value = c->pair_thresh;
   else if (n == "tree_depth") *value = c->tree_depth;
   else if (n == "wide_tree") *value = c->wide_tree;
@@ -1476,7 +1856,7 @@ int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H
   if (rc != DR_OK) return rc;
   if ((rc = collect_time(c, (uint64_t)nframes, samples)) != DR_OK) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return DR_OK;
+  return check_abort(c);
 }
 
 int dr_render_accumulate_async(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
@@ -1500,7 +1880,7 @@ int dr_context_synchronize(dr_context* c) {
   if ((rc = collect_pending(c, c->pending_next)) != DR_OK) return rc;       // older first
   if ((rc = collect_pending(c, c->pending_next ^ 1)) != DR_OK) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return DR_OK;
+  return check_abort(c);
 }
 
 int dr_context_stream(dr_context* c, void** hip_stream) {

@@ -156,7 +156,7 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *   "batch_frames"  most frames one launch of dr_render_accumulate covers (persistent kernel), default 32
  *   "feedback"      1 (default): tiles are started most-expensive-first using the previous launch's costs
  *   "occupancy"     waves per SIMD: 5 (default) or 4 for the persistent kernel, 4 or 6 for the tile kernel
- *   "trav_min"      32 or 48;  "park_min"  0, 8 or 16;  "unroll"  1, 2 (default) or 3   (persistent kernel scheduling)
+ *   "trav_min"      32 or 48;  "park_min"  0, 8 or 16 (default);  "unroll"  1, 2 (default) or 3   (persistent kernel scheduling)
  *   "xcd_regions"   1 (default): one tile queue per XCD, each an image band, with stealing; 0: one queue
  *   "heavy_factor"  with feedback: tiles that cost more than this many times the mean start first (most expensive
  *                   first), all others keep their natural order (default 1: the above-average tiles; 0: no tile is
@@ -170,6 +170,9 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *   "paired"        wide walk, launches with many tiles per wave: 1 = every lane owns two paths (one walked, one waiting to be
  *                   shaded or holding the next ray), phase once "pair_thresh" (32, 48, 56) lanes have one to service; measured
  *                   slower than the default one-path kernel, so 0 by default
+ *   "roles"         wide walk, launches with many tiles per wave: 3, 7 or 6 = workgroups of 3 / 7 trace waves + one shade wave, or 6 + 2,
+ *                   that pass rays and hits through rings in LDS (render_roles_kernel); measured slower than the default
+ *                   kernel, so 0 by default
  *   "wide_tree"     tree under the wide walk, read at dr_context_upload_scene: 1 (default) binned surface-area
  *                   heuristic over the leaf boxes, 0 the reference's own topology (K:1745-1861) collapsed 4-way
  * The environment variable DOGERAY_OPTIONS="name=value,..." applies the same at context creation. */

@@ -309,7 +309,9 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
               {"kernel": 1, "batch_frames": 2, "coop_steps": 16, "coop_lanes": 4},
               {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 48},       # two paths per lane
               {"kernel": 1, "batch_frames": 4, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 32},
-              {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 56}]
+              {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 56},
+              {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 0, "roles": 7},                # trace waves + shade wave(s)
+              {"kernel": 1, "batch_frames": 8, "coop_tiles_per_wave": 0, "roles": 6}, {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "roles": 3}]
     for opts in combos:
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -320,9 +322,9 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         if base is None:
             base = acc
         assert np.array_equal(acc, base), opts
-    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 8, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 8, "coop_lanes": 8, "coop_tiles_per_wave": 32, "paired": 0}.items():
+    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 16, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 8, "coop_lanes": 8, "coop_tiles_per_wave": 32, "paired": 0, "roles": 0}.items():
         ctx.set_option(k, v)
-    assert ctx.get_option("park_min") == 8 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
+    assert ctx.get_option("park_min") == 16 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
     with pytest.raises(dr.DogerayError):
         ctx.set_option("park_min", 7)
     with pytest.raises(dr.DogerayError):
@@ -557,3 +559,22 @@ def test_work_sharing_drain_renders_like_the_oracle(dr, orc, ctx, synth, tmp_pat
         finally:
             ctx.set_option("coop_steps", 8)
             ctx.set_option("coop_lanes", 8)
+
+
+def test_waves_with_roles_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
+    """render_roles_kernel (option "roles", off by default): trace waves and shade waves exchanging rays and hits through LDS rings --
+    every material, textures, spheres, spp > 1 with a wide lens, margins; frames identical to the oracle's."""
+    mb4 = with_settings(os.path.join(synth["dir"], "matball.rts"), str(tmp_path / "mb4.rts"),
+                        "*,0,-2.5,7,0.6,0,-0.5,0,7,50,6,4,0.9,synth_env.ppm,192,128")
+    cases = [(mb4, synth["tex"], 192, 128), (os.path.join(SCENES, "scene.rts"), "", 320, 192), (os.path.join(SCENES, "glass.rts"), "", 200, 120),
+             (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192), (os.path.join(synth["dir"], "city_small.rts"), "", 100, 70)]
+    ctx.set_option("coop_tiles_per_wave", 0)
+    try:
+        for roles in (3, 7, 6):
+            ctx.set_option("roles", roles)
+            for path, tex, W, H in cases:
+                g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, 1, 99, mode=2, kernel=1)
+                _assert_frames(g, r, "%s waves with roles %d" % (os.path.basename(path), roles))
+    finally:
+        ctx.set_option("roles", 0)
+        ctx.set_option("coop_tiles_per_wave", 32)

@@ -1,4 +1,5 @@
-"""Experiment (GPU box): the two-paths-per-lane kernel against the one-path kernel on the bench scene: identical accumulators, ms/frame."""
+"""Experiment (GPU box): the two-paths-per-lane kernel and the waves-with-roles kernel against the one-path kernel on the bench
+scene: identical accumulators, ms/frame, wave-level step counts.  python tools/exp_paired.py [frames] [variants]"""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -10,7 +11,9 @@ st = dr.pack_settings13(s, 1, spp=1)
 W, H = 1920, 1080
 res = {}
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 32
-for name, opts in (("one-path", {"paired": 0}), ("paired 48", {"paired": 1, "pair_thresh": 48}), ("paired 32", {"paired": 1, "pair_thresh": 32}), ("paired 56", {"paired": 1, "pair_thresh": 56})):
+VARIANTS = (("one-path", {"paired": 0, "roles": 0}), ("roles7", {"paired": 0, "roles": 7}), ("roles3", {"paired": 0, "roles": 3}), ("roles6", {"paired": 0, "roles": 6}), ("paired 48", {"paired": 1, "roles": 0, "pair_thresh": 48}))
+if len(sys.argv) > 2: VARIANTS = tuple(v for v in VARIANTS if v[0] in sys.argv[2].split(",") or v[0] == "one-path")
+for name, opts in VARIANTS:
     for k, v in opts.items():
         ctx.set_option(k, v)
     ctx.accum_reset(W, H)
