@@ -94,7 +94,7 @@ void usage() {
 int main(int argc, char** argv) {
   std::string scene_path = "scene.rts", out_path;
   const char* texdir = nullptr;
-  int frames = 64, device = 0, group = 8, width = 0, height = 0, spp = 0, depth = 0, gpus = 1, gather_every = 0;
+  int frames = 64, device = 0, group = 8, width = 0, height = 0, spp = 0, depth = 0, gpus = 0, gather_every = 0;
   uint64_t seed = 1;
   bool quiet = false, have_scene = false, use_cache = false;
   for (int i = 1; i < argc; i++) {
@@ -152,7 +152,7 @@ int main(int argc, char** argv) {
   dr_context* ctx = nullptr;
   dr_group* grp = nullptr;
   const int W = s.width, H = s.height;
-  if (gpus > 1) {
+  if (gpus >= 1) {                       // --gpus given (even 1): the group path
     if (dr_group_create(gpus, nullptr, &grp) != DR_OK) die("cannot create the GPU group");
     if (dr_group_upload_scene(grp, scene) != DR_OK) die("cannot upload the scene");
     if (dr_group_accum_reset(grp, W, H) != DR_OK) die("cannot allocate the accumulators");

@@ -197,7 +197,10 @@ int dr_group_create(int n, const int* device_ordinals, dr_group** out) {
     for (int q = 0; q < r; q++) if (g->device[(size_t)q] == g->device[(size_t)r]) distinct = false;
   }
   const char* tr = getenv("DOGERAY_GROUP_TRANSPORT");
-  g->use_rccl = n > 1 && distinct && !(tr && std::string(tr) == "copy");
+  // DOGERAY_GROUP_TRANSPORT=copy: peer copies even between distinct devices; =rccl: RCCL even for one rank (rehearsal: loads the
+  // library, creates the communicator and sends a buffer to itself, which is all a one-GPU box allows)
+  const bool force_rccl = tr && std::string(tr) == "rccl" && distinct;
+  g->use_rccl = (n > 1 && distinct && !(tr && std::string(tr) == "copy")) || force_rccl;
   auto bail = [&](int rc, const std::string& msg) { set_error(msg); dr_group_destroy(g); return rc; };
   g->ctx.assign((size_t)n, nullptr);
   g->comm.assign((size_t)n, nullptr);
@@ -217,6 +220,23 @@ int dr_group_create(int n, const int* device_ordinals, dr_group** out) {
     g->comms.assign((size_t)n, nullptr);
     ncclResult_t rc = g->rccl.CommInitAll(g->comms.data(), n, g->device.data());
     if (rc != ncclSuccess) { g->comms.clear(); return bail(DR_ERR_DEVICE, std::string("group: ncclCommInitAll: ") + g->rccl.GetErrorString(rc)); }
+    if (force_rccl) {
+      // self-check of the resolved entry points: rank 0 sends 4096 int32 to itself (grouped send + recv on its communication stream)
+      std::vector<int32_t> host(4096), back(4096, 0);
+      for (size_t i = 0; i < host.size(); i++) host[i] = (int32_t)(i * 2654435761u);
+      int32_t *a = nullptr, *b = nullptr;
+      bool ok = hipSetDevice(g->device[0]) == hipSuccess && hipMalloc((void**)&a, host.size() * 4) == hipSuccess && hipMalloc((void**)&b, host.size() * 4) == hipSuccess &&
+                hipMemcpy(a, host.data(), host.size() * 4, hipMemcpyHostToDevice) == hipSuccess && hipMemset(b, 0, host.size() * 4) == hipSuccess;
+      ok = ok && g->rccl.GroupStart() == ncclSuccess;
+      ok = ok && g->rccl.Send(a, host.size(), ncclInt32, 0, g->comms[0], g->comm[0]) == ncclSuccess;
+      ok = ok && g->rccl.Recv(b, host.size(), ncclInt32, 0, g->comms[0], g->comm[0]) == ncclSuccess;
+      ok = ok && g->rccl.GroupEnd() == ncclSuccess;
+      ok = ok && hipStreamSynchronize(g->comm[0]) == hipSuccess && hipMemcpy(back.data(), b, host.size() * 4, hipMemcpyDeviceToHost) == hipSuccess;
+      ok = ok && back == host;
+      if (a) (void)hipFree(a);
+      if (b) (void)hipFree(b);
+      if (!ok) return bail(DR_ERR_DEVICE, "group: RCCL self-check (send to self) failed");
+    }
   } else if (n > 1) {
     for (int r = 1; r < n; r++) {                 // peer copies into rank 0's staging buffer
       if (g->device[(size_t)r] == g->device[0]) continue;

@@ -72,9 +72,13 @@ class StripeGatherer:
     torch's stream behind the gather).  Nothing waits on the host: events order the three stages, two pack buffers and
     two staging buffers alternate, so the gather of one batch runs beside the rendering of the next."""
 
-    def __init__(self, ctx, W, H, world, rank, device, group=None):
+    def __init__(self, ctx, W, H, world, rank, device, group=None, rehearse=False):
+        """rehearse: run pack -> gather even for world == 1 (rank 0 gathers its own stripe into its staging buffer; nothing is
+        written back: with one rank the stripe is the whole frame, which the next batch is already being rendered into):
+        the only way to put the real collective library under these buffers and streams on a one-GPU box."""
         import torch
         self.ctx, self.W, self.H, self.world, self.rank, self.group, self.device = ctx, W, H, world, rank, group, device
+        self.rehearse = rehearse
         gx = W // 8
         run = 8 * H * 3
         self.stride = ((gx + world - 1) // world) * run              # int32 per rank: the largest stripe (rank 0's); a multiple of 4
@@ -88,7 +92,7 @@ class StripeGatherer:
         """Queue pack -> gather -> unpack for the frames rendered so far; returns at once."""
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if self.world == 1 and not self.rehearse:
             return
         slot = self.batch & 1
         self.batch += 1

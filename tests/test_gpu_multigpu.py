@@ -164,3 +164,58 @@ def test_stripe_gatherer_with_a_stand_in_collective(dr, scene, monkeypatch):
     assert np.array_equal(ctxs[0].accum_read(), want)
     for c in ctxs:
         c.close()
+
+
+def test_stripe_gatherer_on_rccl_with_one_rank(dr, scene):
+    """The real collective library under the real buffers and streams: a one-rank RCCL process group (all a one-GPU box allows),
+    StripeGatherer in rehearsal mode -- rank 0 gathers its own packed stripe (with one rank: the whole frame) through
+    torch.distributed (backend nccl = RCCL) into its staging buffers, batch after batch, beside the rendering of the next batch;
+    the last gathered buffer must be the final accumulator, the one before it the accumulator two frames earlier."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from dogeray_amd import multigpu
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group(backend="nccl", init_method="tcp://127.0.0.1:%d" % port, world_size=1, rank=0, device_id=torch.device("cuda", 0))
+    try:
+        s = scene.settings()
+        st = dr.pack_settings13(s, 1)
+        ref = dr.Context(0).upload(scene)
+        ref.accum_reset(W, H)
+        ref.render_accumulate(st, W, H, s.background, 55, 1000003, 6)
+        want = ref.accum_read()
+        ref.close()
+        ctx = dr.Context(0).upload(scene)
+        ctx.accum_reset(W, H)
+        g = multigpu.StripeGatherer(ctx, W, H, 1, 0, torch.device("cuda", 0), rehearse=True)
+        for k in range(3):
+            ctx.render_accumulate_async(st, W, H, s.background, 55 + 2 * k * 1000003, 1000003, 2)
+            g.gather_async()
+        g.finish()
+        assert np.array_equal(ctx.accum_read(), want)
+        n = (W // 8) * 8 * H * 3
+        last = g.stage[(g.batch - 1) & 1][0][:n].cpu().numpy()
+        assert np.array_equal(last, want.reshape(-1)[:n])
+        ref = dr.Context(0).upload(scene)
+        ref.accum_reset(W, H)
+        ref.render_accumulate(st, W, H, s.background, 55, 1000003, 4)
+        prev = g.stage[g.batch & 1][0][:n].cpu().numpy()
+        assert np.array_equal(prev, ref.accum_read().reshape(-1)[:n])
+        ref.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_native_host_application_loads_rccl(dr, synth, tmp_path):
+    """`dogeray --gpus 1` with DOGERAY_GROUP_TRANSPORT=rccl: the group resolves RCCL from librccl.so, creates a one-rank communicator
+    and sends a buffer to itself before rendering (the entry points dr_group uses for N > 1, as far as one GPU can exercise them)."""
+    exe = os.path.join(ROOT, "dogeray_amd", "bin", "dogeray")
+    scene = os.path.join(synth["dir"], "city_small.rts")
+    out = str(tmp_path / "img.ppm")
+    env = dict(os.environ, DOGERAY_GROUP_TRANSPORT="rccl")
+    r = subprocess.run([exe, scene, "--textures", synth["tex"], "--frames", "4", "--gpus", "1", "--out", out], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "RCCL send/recv" in r.stdout and os.path.getsize(out) > 1000
