@@ -75,10 +75,10 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // block, as the parked triangle test is in the threaded walk); its stack lives in the first WIDE_STACK words of
 // the wave's LDS region, the phase stash behind it.
 // COOP (wide walk): build with the work-sharing drain (idle lanes take over subtrees of the rays still walking).  It costs registers
-// and LDS (101 VGPRs, 35 KiB per workgroup: four per CU), so launches whose queue is long enough to hide their tail use the build
+// (90 VGPRs instead of 84) and a block of code in the loop, so launches whose queue is long enough to hide their tail use the build
 // without it (launch_persistent picks).
 template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE, bool COOP = true>
-__global__ __launch_bounds__(256, (WIDE && COOP && OCC > 4) ? 4 : OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
+__global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, const int* __restrict__ region_start,
                                                                      unsigned* __restrict__ pixel_cost) {
   const int lane = threadIdx.x & 63;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, (WIDE && COOP && OCC > 4) ? 4 : OCC) void rend
   // WIDE && COOP: three more words per lane behind the stash -- the shared best hit (64-bit key) and the number of helper lanes of
   // a ray whose subtrees have been handed out (drain phase, below)
   constexpr int SHARE_OFF = (WIDE_STACK + WIDE_STASH) * 64;
-  constexpr int REGION = WIDE ? (WIDE_STACK + WIDE_STASH + (COOP ? 4 : 0)) * 64 : WAVE_LDS_DWORDS;
+  constexpr int REGION = WIDE ? (WIDE_STACK + WIDE_STASH + (COOP ? 3 : 0)) * 64 : WAVE_LDS_DWORDS;
   __shared__ __attribute__((aligned(16))) int wave_lds[4 * REGION];
   int* const my_lds = wave_lds + (threadIdx.x >> 6) * REGION;
   int* const my_stack = my_lds + lane;                             // WIDE: word k of this lane's stack at my_stack[k * 64]
@@ -167,11 +167,10 @@ __global__ __launch_bounds__(256, (WIDE && COOP && OCC > 4) ? 4 : OCC) void rend
       float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? WIDE_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
       if (WIDE) {
         st[0 * 64] = __uint_as_float(ws.top); st[1 * 64] = __int_as_float(ws.sp);
-        st[11 * 64] = inv.x; st[12 * 64] = inv.y; st[13 * 64] = inv.z;
         st[2 * 64] = color.x; st[3 * 64] = color.y; st[4 * 64] = color.z;
         st[5 * 64] = __int_as_float(px); st[6 * 64] = __int_as_float(py); st[7 * 64] = __int_as_float(pcode);
         st[8 * 64] = __int_as_float(frame); st[9 * 64] = __int_as_float(sample);
-        st[10 * 64] = __uint_as_float(steps); st[14 * 64] = __uint_as_float(rstart);
+        st[10 * 64] = __uint_as_float(steps); st[11 * 64] = __uint_as_float(rstart);
         asm volatile("" ::: "memory");
       } else {
         st[0 * 64] = pk.v0x; st[1 * 64] = __uint_as_float(pk.C.x); st[2 * 64] = __uint_as_float(pk.C.y); st[3 * 64] = __uint_as_float(pk.C.z); st[4 * 64] = __uint_as_float(pk.C.w);
@@ -205,7 +204,7 @@ __global__ __launch_bounds__(256, (WIDE && COOP && OCC > 4) ? 4 : OCC) void rend
         color = mk(st[2 * 64], st[3 * 64], st[4 * 64]);
         px = __float_as_int(st[5 * 64]); py = __float_as_int(st[6 * 64]); pcode = __float_as_int(st[7 * 64]);
         frame = __float_as_int(st[8 * 64]); sample = __float_as_int(st[9 * 64]);
-        steps = __float_as_uint(st[10 * 64]); rstart = __float_as_uint(st[14 * 64]);
+        steps = __float_as_uint(st[10 * 64]); rstart = __float_as_uint(st[11 * 64]);
       } else {
         asm volatile("" ::: "memory");
         color = mk(st[14 * 64], st[15 * 64], st[16 * 64]);
@@ -301,9 +300,9 @@ __global__ __launch_bounds__(256, (WIDE && COOP && OCC > 4) ? 4 : OCC) void rend
       if (WIDE) {
         asm volatile("" ::: "memory");
         ws.top = __float_as_uint(st[0 * 64]); ws.sp = __float_as_int(st[1 * 64]);
-        inv = mk(st[11 * 64], st[12 * 64], st[13 * 64]);
-        if (fresh_ray) { inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z); ws.top = 0u; ws.sp = 0; ws.sb = 0; }
-        wr = wide_ray(path.rayo, inv, P.wide_pmax);            // recomputed for every lane (a dozen instructions) rather than stashed
+        if (fresh_ray) { ws.top = 0u; ws.sp = 0; ws.sb = 0; }
+        inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);      // 1/direction and the folded test's margins are
+        wr = wide_ray(path.rayo, inv, P.wide_pmax);                                        // recomputed for every lane rather than stashed
       } else {
         asm volatile("" ::: "memory");
         pk.v0x = st[0 * 64]; pk.C = u32x4{__float_as_uint(st[1 * 64]), __float_as_uint(st[2 * 64]), __float_as_uint(st[3 * 64]), __float_as_uint(st[4 * 64])};
@@ -1454,7 +1453,6 @@ void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, 
   if (traversal_of(c) == DR_TRAVERSAL_WIDE) {
     // the cooperative drain shortens a launch's tail; with many tiles per wave the tail does not show and the leaner build is faster
     const bool coop = P.coop_steps > 0 && (long long)work < (long long)c->coop_tiles_per_wave * blocks * 4;
-    if (coop && !c->count && OCC > 4) grid = dim3((unsigned)(blocks > c->num_cus * 4 ? c->num_cus * 4 : blocks));      // that build's LDS admits four workgroups per CU
     const bool degenerate = P.max_depth <= 0 || !(P.spp_f > 0.0f);
     if (c->paired && !c->count && !coop && !degenerate && OCC == 5 && ensure_paths(c, (size_t)blocks * 4)) {
       // long launch: two paths per lane

@@ -4,6 +4,7 @@
 //   g++ -std=c++17 -O2 -ffp-contract=off -I dogeray_amd/csrc -I include -o /tmp/widewalk tools/study_wide_walk.cpp \
 //       dogeray_amd/csrc/linearise.cpp dogeray_amd/csrc/wide_builder.cpp dogeray_amd/csrc/rts_reader.cpp \
 //       dogeray_amd/csrc/bvh_builder.cpp dogeray_amd/csrc/capi_host.cpp -pthread && /tmp/widewalk scene.rts 20000 [tree_mode]
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -99,6 +100,50 @@ static void wide_hit(const std::vector<DevUnit>& rec, float pmax, const float o[
   }
 }
 
+// exact (unquantised) box of every record: a leaf's own, a node's = union of its children's -- to price the 8-bit quantisation
+static void exact_boxes(const std::vector<DevUnit>& rec, size_t idx, bool leaf, std::vector<float>& bx) {
+  const uint32_t* w = reinterpret_cast<const uint32_t*>(&rec[idx * WIDE_UNITS]);
+  const float* f = reinterpret_cast<const float*>(w);
+  float* b = &bx[idx * 6];
+  if (leaf) { for (int a = 0; a < 3; a++) { b[a] = f[a]; b[3 + a] = f[4 + a]; } return; }
+  const unsigned base = w[3] & 0xffffffu, valid = w[7] & 15u, leafmask = (w[7] >> 4) & 15u;
+  for (int a = 0; a < 3; a++) { b[a] = INFINITY; b[3 + a] = -INFINITY; }
+  for (int k = 0; k < 4; k++) if (valid >> k & 1) {
+    exact_boxes(rec, base + k, leafmask >> k & 1, bx);
+    for (int a = 0; a < 3; a++) { b[a] = fminf(b[a], bx[(base + k) * 6 + a]); b[3 + a] = fmaxf(b[3 + a], bx[(base + k) * 6 + 3 + a]); }
+  }
+}
+static void exact_hit(const std::vector<DevUnit>& rec, const std::vector<float>& bx, const float o[3], const float d[3], const float inv[3], long& nodes, long& leaves) {
+  float best_t = 1e7f; unsigned best_slot = ~0u;
+  struct E { unsigned idx; bool leaf; };
+  std::vector<E> st{{0, false}};
+  while (!st.empty()) {
+    E e = st.back(); st.pop_back();
+    const uint32_t* w = reinterpret_cast<const uint32_t*>(&rec[(size_t)e.idx * WIDE_UNITS]);
+    const float* f = reinterpret_cast<const float*>(w);
+    float dist;
+    if (!(slab(o, inv, &bx[(size_t)e.idx * 6], &bx[(size_t)e.idx * 6 + 3], dist) && dist <= best_t)) continue;      // pruned at pop time too: the ideal
+    if (e.leaf) {
+      leaves++;
+      const int info = (int)w[3];
+      const float v0[3] = {f[7], f[8], f[9]}, e1[3] = {f[10], f[11], f[12]}, e2[3] = {f[13], f[14], f[15]};
+      float t = ((info >> WALK_SLOT_BITS) & 3) == WALK_KIND_TRIANGLE ? tri(o, d, v0, e1, e2) : -1;
+      const unsigned slot = (unsigned)(info & ((1 << WALK_SLOT_BITS) - 1));
+      if (t > 0 && t < 10000.0f && (t < best_t || (t == best_t && slot < best_slot))) { best_t = t; best_slot = slot; }
+      continue;
+    }
+    nodes++;
+    const unsigned base = w[3] & 0xffffffu, valid = w[7] & 15u, leafmask = (w[7] >> 4) & 15u;
+    struct C { float d; unsigned idx; bool leaf; } c[4]; int n = 0;
+    for (int k = 0; k < 4; k++) if (valid >> k & 1) {
+      float dk;
+      if (slab(o, inv, &bx[(size_t)(base + k) * 6], &bx[(size_t)(base + k) * 6 + 3], dk) && dk <= best_t) c[n++] = {dk, base + (unsigned)k, (bool)(leafmask >> k & 1)};
+    }
+    std::sort(c, c + n, [](const C& x, const C& y) { return x.d > y.d; });      // farthest first onto the stack
+    for (int k = 0; k < n; k++) st.push_back({c[k].idx, c[k].leaf});
+  }
+}
+
 int main(int argc, char** argv) {
   if (argc < 2) return 1;
   dr_scene sc; sc.host.settings = default_settings();
@@ -123,6 +168,8 @@ int main(int argc, char** argv) {
   std::mt19937 rng2(3); std::uniform_real_distribution<float> U(0, 1);
   int nr = argc > 2 ? atoi(argv[2]) : 20000;
   long bin_int = 0, bin_leaf = 0, bin_tests = 0, rays = 0; WideStats ws;
+  std::vector<float> bx(img.wide.size() / WIDE_UNITS * 6); exact_boxes(img.wide, 0, false, bx);
+  long ex_nodes = 0, ex_leaves = 0;
   for (int r = 0; r < nr; r++) {
     float o[3], d[3], inv[3];
     float s = U(rng2), t = U(rng2);
@@ -137,6 +184,7 @@ int main(int argc, char** argv) {
           else { bin_int++; node = h ? b.hit_node : b.miss_node; } } }
       float wb; int wsl;
       wide_hit(img.wide, img.wide_pmax, o, d, inv, wb, wsl, ws);
+      exact_hit(img.wide, bx, o, d, inv, ex_nodes, ex_leaves);
       if (wsl != bs || (bs >= 0 && wb != best)) { printf("MISMATCH ray %d bounce %d: wide %d %g vs reference %d %g\n", r, bounce, wsl, wb, bs, best); return 1; }
       rays++;
       if (bs < 0) break;
@@ -149,5 +197,6 @@ int main(int argc, char** argv) {
   }
   printf("%ld rays, hits identical.  reference walk: %.1f internal + %.1f leaf visits, %.2f primitive tests per ray;  wide walk (tree mode %d): %.1f node + %.1f leaf records, %.2f primitive tests per ray, deepest stack %ld; fetched although already farther than the best t when popped: %.2f nodes + %.2f leaves per ray; children entered by the folded test only: %.3f per ray\n",
          rays, (double)bin_int / rays, (double)bin_leaf / rays, (double)bin_tests / rays, mode, (double)ws.nodes / rays, (double)ws.leaves / rays, (double)ws.tests / rays, ws.maxsp, (double)ws.cull_nodes / rays, (double)ws.cull_leaves / rays, (double)ws.extra_children / rays);
+  printf("the same tree with exact child boxes, fully sorted children and pruning at pop time (the ideal this layout approximates): %.1f node + %.1f leaf records per ray\n", (double)ex_nodes / rays, (double)ex_leaves / rays);
   return 0;
 }
