@@ -31,7 +31,7 @@ static float tri(const float o[3], const float d[3], const float* v0, const floa
   float t = f*(e2[0]*q[0]+e2[1]*q[1]+e2[2]*q[2]); return t > 1e-4f ? t : -1;
 }
 
-struct WideStats { long nodes = 0, leaves = 0, tests = 0, maxsp = 0, cull_nodes = 0, cull_leaves = 0, cull_entry = 0, extra_children = 0; };
+struct WideStats { long nodes = 0, leaves = 0, tests = 0, maxsp = 0, cull_nodes = 0, cull_leaves = 0, cull_entry = 0, extra_children = 0, leafkids[5] = {0, 0, 0, 0, 0}; };
 
 static void wide_hit(const std::vector<DevUnit>& rec, float pmax, const float o[3], const float d[3], const float inv[3], float& best_t, int& best_slot, WideStats& ws) {
   best_t = 1e7f; best_slot = -1;
@@ -80,6 +80,7 @@ static void wide_hit(const std::vector<DevUnit>& rec, float pmax, const float o[
       mask &= valid; mask_plain &= valid;
       if (mask_plain & ~mask) { printf("FOLDED TEST NOT CONSERVATIVE: plain %x folded %x\n", mask_plain, mask); exit(3); }
       ws.extra_children += __builtin_popcount(mask & ~mask_plain);
+      if (leafmask & valid) ws.leafkids[__builtin_popcount(mask & leafmask)]++;
       if (mask) {
         int near = (int)(key & 3u);
         if (!((mask >> near) & 1u)) near = __builtin_ctz(mask);
@@ -197,6 +198,7 @@ int main(int argc, char** argv) {
   }
   printf("%ld rays, hits identical.  reference walk: %.1f internal + %.1f leaf visits, %.2f primitive tests per ray;  wide walk (tree mode %d): %.1f node + %.1f leaf records, %.2f primitive tests per ray, deepest stack %ld; fetched although already farther than the best t when popped: %.2f nodes + %.2f leaves per ray; children entered by the folded test only: %.3f per ray\n",
          rays, (double)bin_int / rays, (double)bin_leaf / rays, (double)bin_tests / rays, mode, (double)ws.nodes / rays, (double)ws.leaves / rays, (double)ws.tests / rays, ws.maxsp, (double)ws.cull_nodes / rays, (double)ws.cull_leaves / rays, (double)ws.extra_children / rays);
+  printf("nodes with leaf children, by how many of them the ray enters: 0: %ld  1: %ld  2: %ld  3: %ld  4: %ld\n", ws.leafkids[0], ws.leafkids[1], ws.leafkids[2], ws.leafkids[3], ws.leafkids[4]);
   printf("the same tree with exact child boxes, fully sorted children and pruning at pop time (the ideal this layout approximates): %.1f node + %.1f leaf records per ray\n", (double)ex_nodes / rays, (double)ex_leaves / rays);
   return 0;
 }
