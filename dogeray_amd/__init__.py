@@ -118,6 +118,9 @@ _API = [
     ("dr_stats_enable_counters", C.c_int, [_VP, C.c_int]),
     ("dr_stats_reset", C.c_int, [_VP]),
     ("dr_stats_get", C.c_int, [_VP, C.POINTER(DrStats)]),
+    ("dr_stats_wave_log", C.c_int, [_VP, C.POINTER(C.c_ulonglong), C.c_int, C.POINTER(C.c_int)]),
+    ("dr_stats_pixel_cost", C.c_int, [_VP, C.POINTER(C.c_uint), C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("dr_stats_pixel_times", C.c_int, [_VP, C.POINTER(C.c_uint), C.c_size_t, C.POINTER(C.c_size_t)]),
     ("dr_context_probe_gather", C.c_int, [_VP, C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
     ("dr_kat_rng", C.c_int, [_VP, C.c_uint64, C.c_int, _VP]),
     ("dr_kat_aabb", C.c_int, [_VP, C.c_int] + [_VP] * 6),
@@ -381,6 +384,35 @@ class Context:
         s = DrStats()
         _check(lib().dr_stats_get(self._h, C.byref(s)))
         return s.as_dict()
+
+    def wave_log(self, max_waves=16384):
+        """(n, 16) uint64: begin, queue-empty, end stamps (100 MHz ticks) and iterations after the queue was empty, per wave of the
+        last persistent launch; needs set_option("wave_log", 1) before the launch."""
+        out = np.zeros((max_waves, 16), dtype=np.uint64)
+        n = C.c_int()
+        _check(lib().dr_stats_wave_log(self._h, out.ctypes.data_as(C.POINTER(C.c_ulonglong)), max_waves, C.byref(n)))
+        return out[:n.value]
+
+    def pixel_cost(self, W, H):
+        """(W, H) uint32 node steps per pixel of the last frame the persistent kernel recorded (empty array: none yet)."""
+        gx, gy = (W + 7) // 8, (H + 7) // 8
+        out = np.zeros(gx * gy * 64, dtype=np.uint32)
+        n = C.c_size_t()
+        _check(lib().dr_stats_pixel_cost(self._h, out.ctypes.data_as(C.POINTER(C.c_uint)), out.size, C.byref(n)))
+        if n.value < out.size:
+            return np.zeros((0, 0), dtype=np.uint32)
+        return out.reshape(gx, gy, 8, 8).transpose(0, 2, 1, 3).reshape(gx * 8, gy * 8)[:W, :H]
+
+    def pixel_times(self, W, H):
+        """Experiment builds only: two (W, H) uint32 maps, start and end of every pixel of the last single-frame launch in 100 MHz
+        ticks since the launch began (None in the product build)."""
+        gx, gy = (W + 7) // 8, (H + 7) // 8
+        out = np.zeros(2 * gx * gy * 64, dtype=np.uint32)
+        n = C.c_size_t()
+        _check(lib().dr_stats_pixel_times(self._h, out.ctypes.data_as(C.POINTER(C.c_uint)), out.size, C.byref(n)))
+        if n.value < out.size:
+            return None
+        return tuple(h.reshape(gx, gy, 8, 8).transpose(0, 2, 1, 3).reshape(gx * 8, gy * 8)[:W, :H] for h in (out[:gx * gy * 64], out[gx * gy * 64:]))
 
     def probe_gather(self, hot_records=0, iters=2000):
         """Records/s of divergent, dependent 64-byte fetches from the resident wide array (bench.py roofline.gather)."""

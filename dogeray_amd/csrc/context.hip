@@ -77,6 +77,10 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // COOP (wide walk): build with the work-sharing drain (idle lanes take over subtrees of the rays still walking).  It costs registers
 // (90 VGPRs instead of 84) and a block of code in the loop, so launches whose queue is long enough to hide their tail use the build
 // without it (launch_persistent picks).
+constexpr int MAX_REGIONS = 8;
+constexpr int WAVE_LOG_WAVES = 16384;    // waves the wave log (option wave_log) has room for
+constexpr size_t PIXEL_LOG_WORDS = DR_WAVE_LOG_DETAIL ? (size_t)2 * 4096 * 4096 : 0;   // experiment builds: start and end stamp of every pixel behind the wave log
+
 template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE, bool COOP = true>
 __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, const int* __restrict__ region_start,
@@ -117,9 +121,14 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   // once its own is empty.  Region r owns positions [region_start[r], region_start[r+1]) of the order.
   int cur_tile = ntiles, cur_frame = 0;        // chunk being handed out; ntiles = none
   int cur_next = 64;               // next unassigned lane-in-tile of cur_tile (64 = exhausted: fetch first)
+  int cur_limit = 64;              // ... and where this wave's share of cur_tile ends (split tiles: a part of the tile)
+  bool cur_split = false;
+  // tiles at the head of the order that are handed out in P.split_parts parts (work-sharing build, one queue, order from feedback)
+  // (launches of ONE frame: with several frames in the queue the long pixels of one overlap the bulk of the others anyway, and waves that hold cost throughput)
+  const int nsplit = WIDE && COOP && region_start && P.split_parts > 1 && P.regions == 1 && P.batch == 1 ? region_start[MAX_REGIONS + 1] : 0;
   int region = 0, regions_left = P.regions;
   if (P.regions > 1) region = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % (unsigned)P.regions);   // HW_REG_XCC_ID, 4 bits
-  (void)wave_id; (void)nwork;
+  (void)nwork;
   // per-lane path slot
   Trav tr; tr.node = -2; tr.best_t = 0; tr.best_slot = -1;
   Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
@@ -138,19 +147,34 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   unsigned long long r_begin = 0;
   // wave lifetime in shader cycles and in 100 MHz ticks, every build: two clock reads per wave, written to the statistics buffer only
   t_begin = __builtin_readcyclecounter(); r_begin = __builtin_amdgcn_s_memrealtime();
+  bool held = false;               // COOP: this wave has pixels of a split tile and fetches no new tiles while they live
+  unsigned long long r_empty = 0, n_after = 0;      // wave log (option wave_log): when this wave first found the queue empty, loop iterations since
+  unsigned long long d_iters = 0;      // loop iterations of the wave
+  unsigned long long d_want_give = 0, d_idle = 0, d_owner_walk = 0, d_share_iters = 0, d_wait_owner = 0, d_pending = 0;   // ... of the iterations in which the sharing block ran: givers, idle lanes, walking owners, owners waiting for helpers, lanes waiting for a phase
+  unsigned long long d_phases = 0, d_given = 0, d_walking = 0, d_phase_ticks = 0;      // -DDR_WAVE_LOG_DETAIL builds: phases, hand-overs, walking lanes summed, ticks inside phases, all after the queue ran empty
   ParkedLeaf pk; pk.v0x = 0; pk.C = pk.D = u32x4{0, 0, 0, 0}; pk.info = 0; pk.parked = false;   // PARK_MIN > 0 only
   for (;;) {
     const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;
+    if (r_empty != 0ull) n_after++;
+    if (DR_WAVE_LOG_DETAIL) d_iters++;
+    if (DR_WAVE_LOG_DETAIL && r_empty != 0ull) d_walking += (unsigned long long)__popcll(__ballot(tr.node >= 0));
     // (a wave that only drains -- queue empty, nobody waiting to be shaded or refilled -- skips the phase: its stash/restore would be
     // paid on every iteration of the launch's tail)
     if (WIDE && COOP) {
       // a helper whose subtree is done reports (its best is in the key already) and is idle again; an owner whose own part is
       // done takes the shared result once its last helper has reported
-      if (tr.node == -1 && share >= 0 && share < 64) { atomicMin(&share_key[share], hit_key(tr.best_t, tr.best_slot)); atomicSub(&share_pend[share], 1u); tr.node = -3; share = -1; }
+      // (the pending word: helpers still out in the low 8 bits; above them the node steps the helpers have spent on this pixel's rays,
+      // which the owner adds to its own when it takes the result -- the cost fed back for a pixel is all the work it caused)
+      if (tr.node == -1 && share >= 0 && share < 64) {
+        atomicMin(&share_key[share], hit_key(tr.best_t, tr.best_slot));
+        atomicAdd(&share_pend[share], (((steps - rstart - (unsigned)P.coop_steps) & 0xffffu) << 8) - 1u);
+        tr.node = -3; share = -1;
+      }
       if (tr.node == -1 && share == 64) {
         atomicMin(&share_key[lane], hit_key(tr.best_t, tr.best_slot));      // its own last improvement may be newer than the key
-        if (share_pend[lane] == 0u) {
+        if ((share_pend[lane] & 0xffu) == 0u) {
+          steps += share_pend[lane] >> 8;
           const unsigned long long k = share_key[lane];
           tr.best_t = __uint_as_float((unsigned)(k >> 32)); tr.best_slot = (int)(unsigned)k;
           share = -1;
@@ -158,9 +182,12 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
     }
     const bool waits_for_helpers = WIDE && COOP && share == 64;      // (only ever true with tr.node == -1 here or while still walking)
-    if (__popcll(walking) < TRAV_MIN && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers) || tr.node == -2) != 0ull)) {
+    // (a holding wave -- long pixels, helpers walking for them -- shades as soon as a ray is finished: its pixels' latency is the point)
+    if ((__popcll(walking) < TRAV_MIN || (WIDE && COOP && held)) && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers) || tr.node == -2) != 0ull)) {
       unsigned long long t0 = 0;
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
+      unsigned long long d_t0 = 0;
+      if (DR_WAVE_LOG_DETAIL && r_empty != 0ull) { d_phases++; d_t0 = __builtin_amdgcn_s_memrealtime(); }
       const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked) && !waits_for_helpers;
       if (COUNT) n_shaded += __popcll(__ballot(shade_me));
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
@@ -232,50 +259,76 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         } else {
           if (px >= 0) {
             store_pixel(P, px, py, color);
-            if (pixel_cost) pixel_cost[pcode] = steps;
+            if (pixel_cost) pixel_cost[pcode & 0x7fffffff] = steps;
+            if (DR_WAVE_LOG_DETAIL && P.wave_log)      // experiment builds: when the pixel was finished (100 MHz ticks since the wave began, i.e. since the launch)
+              reinterpret_cast<unsigned*>(P.wave_log + (size_t)WAVE_LOG_WAVES * 16)[(size_t)ntiles * 64 + (pcode & 0x7fffffff)] = (unsigned)(__builtin_amdgcn_s_memrealtime() - r_begin);
           }
           px = -1;
           want_pixel = true;
         }
       }
+      if (WIDE && COOP && nsplit > 0) {
+        // A wave that took a part of a split tile holds -- fetches no further tile -- while one of those pixels lives: its lanes, as
+        // their own pixels end, are helpers that take over subtrees of the long pixels' rays (the work-sharing block below); once
+        // the pixels are done the lanes go back to fetching.
+        held = __ballot(px >= 0 && pcode < 0) != 0ull;
+        if (!held && tr.node == -3 && share < 0 && !(cur_tile >= ntiles && regions_left == 0)) { tr.node = -2; want_pixel = true; }
+      }
       unsigned long long need = __ballot(want_pixel);
       while (need != 0ull) {
-        if (cur_next >= 64) {                      // wave-uniform: fetch the next chunk (tile, frame)
+        if (cur_next >= cur_limit) {               // wave-uniform: fetch the next chunk (tile, frame)
+          if (WIDE && COOP && held) {              // holding: no new tile, the lanes asking become helpers
+            if (want_pixel) { tr.node = -3; want_pixel = false; }
+            break;
+          }
           cur_tile = ntiles;
+          cur_next = 0; cur_limit = 64; cur_split = false;
           while (regions_left > 0) {
             const int r0 = region_start ? region_start[region] : P.region_start[region];
             const int r1 = region_start ? region_start[region + 1] : P.region_start[region + 1];
             unsigned t = 0;
             if (lane == 0) t = atomicAdd(tile_counter + region, 1u);
             const int q = (int)__builtin_amdgcn_readfirstlane(t);
-            if (q < (r1 - r0) * P.batch) {
-              const int tt = q / P.batch;
+            if (q < (r1 - r0 + nsplit * (P.split_parts - 1)) * P.batch) {
+              int tt = q / P.batch;
               cur_frame = q - tt * P.batch;
+              if (WIDE && COOP && tt < nsplit * P.split_parts) {
+                // one of the tiles whose pixels were the longest of the last frame (the head of the order): this wave takes
+                // 64 / split_parts of its pixels and holds (no further tile) until they are done -- its other lanes help with
+                // their rays from the start
+                const int part = tt % P.split_parts, width = 64 / P.split_parts;
+                tt /= P.split_parts;
+                cur_next = part * width; cur_limit = cur_next + width; cur_split = true; held = true;
+              } else {
+                tt -= nsplit * (P.split_parts - 1);
+              }
               cur_tile = tile_order ? tile_order[r0 + tt] : r0 + tt;
               break;
             }
             region = region + 1 == P.regions ? 0 : region + 1;   // this band is done: help with the next one
             regions_left--;
           }
-          cur_next = 0;
         }
         if (cur_tile >= ntiles) {                  // frame exhausted: retire the lanes still asking
           if (want_pixel) { tr.node = -3; want_pixel = false; }
+          if (r_empty == 0ull) r_empty = __builtin_amdgcn_s_memrealtime();
           break;
         }
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
-        const int avail = 64 - cur_next;
+        const int avail = cur_limit - cur_next;
         if (want_pixel && rank < avail) {
           const int l = cur_next + rank;
           const int col = cur_tile / P.gy, by = cur_tile - col * P.gy;
           px = (P.stripe_rem + col * P.stripe_mod) * 8 + (l >> 3);
           py = by * 8 + (l & 7);
-          pcode = cur_tile * 64 + l;
+          pcode = (cur_tile * 64 + l) | (cur_split ? (int)0x80000000 : 0);      // sign bit: pixel of a split tile (its wave holds while it lives)
           frame = cur_frame;
           steps = 0;
           sample = 0;
           color = mk(0, 0, 0);
           want_pixel = false;
+          if (DR_WAVE_LOG_DETAIL && P.wave_log)        // ... and when it was started
+            reinterpret_cast<unsigned*>(P.wave_log + (size_t)WAVE_LOG_WAVES * 16)[pcode & 0x7fffffff] = (unsigned)(__builtin_amdgcn_s_memrealtime() - r_begin);
         }
         const int n = __popcll(need);
         cur_next += n < avail ? n : avail;
@@ -312,22 +365,32 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         if (fresh_ray) inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
       }
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
+      if (DR_WAVE_LOG_DETAIL && d_t0 != 0ull) d_phase_ticks += __builtin_amdgcn_s_memrealtime() - d_t0;
       if (__ballot(tr.node != -3) == 0ull) break;
     }
-    if (WIDE && COOP && !COUNT && P.coop_steps > 0 && cur_tile >= ntiles) {
-      // ---- draining (the queue is empty): lanes without a pixel take over subtrees of the rays that still walk.  A walking lane
+    if (WIDE && COOP && !COUNT && P.coop_steps > 0 && (cur_tile >= ntiles || held)) {
+      // ---- draining (the queue is empty), or holding (pixels of a split tile, see the refill above): lanes without a pixel take over subtrees of the rays that still walk.  A walking lane
       // hands the OLDEST word of its stack (the children of a node near the root that it entered but has not visited: the
       // largest piece of work it owns) to an idle lane, which walks it with the same ray.  All lanes of one ray keep the best
       // hit in one LDS word (ds_min_u64 on the (t, slot) key: the lexicographic minimum whatever the order) and prune
       // against it; the owner shades when its own part and every helper's is done.  A ray that would cost one lane hundreds
       // of dependent steps is spread over the idle lanes at the cost of one hand-over per piece -- every leaf is still
       // tested by exactly one lane, with the reference's box and arithmetic, against a bound no smaller than the final t.
+      for (int round = 0; round < P.coop_rounds; round++) {      // (a lane that has just taken a word over may hand part of it on in the next round)
       const unsigned long long idle = __ballot(tr.node == -3);
       const bool can_give = tr.node >= 0 && (ws.sp > ws.sb || ws.top != 0u) && (int)(steps - rstart) >= P.coop_steps;
       const unsigned long long givers = __ballot(can_give);
       const int n_idle = (int)__popcll(idle), n_give = (int)__popcll(givers);
       const int n = n_idle < n_give ? n_idle : n_give;
-      if (n > 0) {
+      if (DR_WAVE_LOG_DETAIL && round == 0) {
+        d_share_iters++; d_want_give += (unsigned long long)n_give; d_idle += (unsigned long long)n_idle;
+        d_owner_walk += (unsigned long long)__popcll(__ballot(tr.node >= 0 && px >= 0));
+        d_wait_owner += (unsigned long long)__popcll(__ballot(tr.node == -1 && share == 64));
+        d_pending += (unsigned long long)__popcll(__ballot((tr.node == -1 && share != 64) || tr.node == -2));
+      }
+      if (n == 0) break;
+      {
+        if (DR_WAVE_LOG_DETAIL) d_given += (unsigned long long)n;
         int* const xch = my_lds + WIDE_STACK * 64;                 // the phase stash is free between phases: 8 words per hand-over
         const int rank_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(givers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)givers, 0u));
         const int rank_i = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
@@ -357,7 +420,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           wide_pop(tr, ws, my_stack);                              // the first pending child of the word
           rstart = steps - (unsigned)P.coop_steps;                 // a helper may hand on at once
         }
-        __builtin_amdgcn_wave_barrier();                           // the exchange words are read before a phase may overwrite them
+        __builtin_amdgcn_wave_barrier();                           // the exchange words are read before a phase (or the next round) may overwrite them
+      }
       }
       // lanes of a shared ray: publish an improvement, take over a better bound
       if (tr.node >= 0 && share >= 0) {
@@ -392,7 +456,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       const bool at_leaf = tr.node >= 0 && (tr.node & 1);
       const unsigned long long leaves = __ballot(at_leaf);
       const unsigned long long nodes = __ballot(tr.node >= 0 && !(tr.node & 1));
-      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes == 0ull || cur_tile >= ntiles);
+      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes == 0ull || cur_tile >= ntiles || held);
       if (COUNT) { n_leafstep += do_leaves; n_nodestep += nodes != 0ull; }
       if (tr.node >= 0 && (!at_leaf || do_leaves)) {
         if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
@@ -406,7 +470,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         const bool at_leaf2 = tr.node >= 0 && (tr.node & 1);
         const unsigned long long leaves2 = __ballot(at_leaf2);
         const unsigned long long nodes2 = __ballot(tr.node >= 0 && !(tr.node & 1));
-        const bool do_leaves2 = leaves2 != 0ull && ((int)__popcll(leaves2) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes2 == 0ull || cur_tile >= ntiles);
+        const bool do_leaves2 = leaves2 != 0ull && ((int)__popcll(leaves2) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes2 == 0ull || cur_tile >= ntiles || held);
         if (COUNT) { n_leafstep += do_leaves2; n_nodestep += nodes2 != 0ull; }
         if (tr.node >= 0 && (!at_leaf2 || do_leaves2)) {
           if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
@@ -453,8 +517,14 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
     }
   }
   if (lane == 0) {
+    const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
     atomicAdd(&P.counters[8], __builtin_readcyclecounter() - t_begin);
-    atomicAdd(&P.counters[15], __builtin_amdgcn_s_memrealtime() - r_begin);      // 100 MHz ticks: wave cycles / this = shader clock / 100 MHz
+    atomicAdd(&P.counters[15], r_end - r_begin);      // 100 MHz ticks: wave cycles / this = shader clock / 100 MHz
+    if (P.wave_log) {
+      unsigned long long* const w = P.wave_log + (size_t)wave_id * 16;
+      w[0] = r_begin; w[1] = r_empty; w[2] = r_end; w[3] = n_after; w[4] = d_phases; w[5] = d_given; w[6] = d_walking; w[7] = d_phase_ticks;
+      w[8] = d_want_give; w[9] = d_idle; w[10] = d_owner_walk; w[11] = d_share_iters; w[12] = d_wait_owner; w[13] = d_pending; w[14] = d_iters;
+    }
   }
   if (COUNT && lane == 0) {
     atomicAdd(&P.counters[9], t_phase);
@@ -1056,9 +1126,8 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const unsigned* __restri
 // launch, so they start first; then all other tiles in their natural order, so that the waves of an XCD walk
 // their band coherently (neighbouring tiles see neighbouring parts of the scene).
 constexpr int ORDER_BUCKETS = 256;
-constexpr int MAX_REGIONS = 8;
 __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __restrict__ tile_cost, int* __restrict__ order,
-                                                           int* __restrict__ region_start, int ntiles, int regions, int heavy_factor) {
+                                                           int* __restrict__ region_start, int ntiles, int regions, int heavy_factor, int split_steps, int split_limit) {
   __shared__ unsigned hist[MAX_REGIONS * ORDER_BUCKETS];   // expensive tiles per (region, cost class)
   __shared__ unsigned base[MAX_REGIONS * ORDER_BUCKETS];
   __shared__ unsigned light_in_region[MAX_REGIONS], light_before[MAX_REGIONS], heavy_in_region[MAX_REGIONS];
@@ -1087,8 +1156,14 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __rest
     unsigned b = tile_cost[t] >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
     return region_of(t) * ORDER_BUCKETS + (ORDER_BUCKETS - 1 - (int)b);      // ascending key = region, then most expensive first
   };
+  // tiles whose longest pixel took at least split_steps node steps (a whole cost class: they are a prefix of the order when there is
+  // one region): short launches hand them out in parts (render_persistent_kernel, nsplit)
+  __shared__ unsigned split_tiles;
+  if (tid == 0) split_tiles = 0;
+  __syncthreads();
   unsigned my_light = 0;
   for (int t = t0; t < t1; t++) {
+    if (heavy(t) && regions == 1 && split_steps > 0 && (tile_cost[t] >> 4) >= (unsigned)(split_steps >> 4)) atomicAdd(&split_tiles, 1u);
     if (heavy(t)) { atomicAdd(&hist[key_of(t)], 1u); atomicAdd(&heavy_in_region[region_of(t)], 1u); }
     else { my_light++; atomicAdd(&light_in_region[region_of(t)], 1u); }
   }
@@ -1107,6 +1182,7 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __rest
       lights += light_in_region[r];
     }
     region_start[regions] = (int)pos;
+    region_start[MAX_REGIONS + 1] = (int)split_tiles < split_limit ? (int)split_tiles : split_limit;      // (any prefix of the order will do)
   }
   __syncthreads();
   unsigned light_rank = scan[tid];                      // global rank of this thread's first light tile
@@ -1286,9 +1362,14 @@ struct dr_context {
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
   int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural, -1 = all by cost)
-  int coop_steps = 8;       // persistent kernel, drain phase: rays older than this many steps are shared with idle lanes / finished cooperatively (0 = off)
+  int coop_steps = 2;       // persistent kernel, drain phase: rays older than this many steps are shared with idle lanes / finished cooperatively (0 = off)
   int coop_tiles_per_wave = 32;   // wide walk: launches with fewer tiles per wave than this run the build with the work-sharing drain
   int coop_lanes = 8;       // ... in waves with at most this many lanes still walking
+  int split_parts = 8;      // short launches: the tiles with last frame's longest pixels are handed out in this many parts (1, 2, 4, 8), the rest of each wave helps
+  int split_steps = 400;    // ... tiles whose longest pixel took at least this many node steps (multiple of 16)
+  int coop_rounds = 2;      // work sharing: hand-over rounds per loop iteration
+  int wave_log_on = 0;      // persistent kernel writes begin / queue-empty / end stamps of every wave (dr_stats_wave_log)
+  unsigned long long* wave_log = nullptr; int wave_log_waves = 0;
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
   float cur_settings[13] = {0};
   dr_stats stats;
@@ -1353,6 +1434,7 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims; P.shade = c->shade; P.tex = c->tex; P.texels = c->texels;
   P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax;
   P.counters = c->counters;
+  P.wave_log = c->wave_log_on ? c->wave_log : nullptr;
   float aspect = float(W / st[11]) / float(H / st[11]);           // K:1016 (int / float)
   float fov = (float)((double)st[8] * M_PI / 180);                // K:1020
   float vh = (float)(2.0 * (double)tanf(fov / 2));                // K:1023
@@ -1383,7 +1465,7 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   P.backtex = backtex;
   P.batch = 1;
   P.batch_seed_stride = 0;
-  P.coop_steps = c->coop_steps;
+  P.coop_steps = c->coop_steps; P.coop_rounds = c->coop_rounds; P.split_parts = c->split_parts;
   P.coop_lanes = c->coop_lanes;
   {
     const int tiles = P.ncols * P.gy;
@@ -1444,11 +1526,14 @@ bool launch_roles(dr_context* c, const RenderParams& P, unsigned* counter) {
 }
 
 template <int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL = 1>
-void launch_persistent(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pixel_cost) {
+void launch_persistent(dr_context* c, const RenderParams& P_in, unsigned* counter, const int* order, unsigned* pixel_cost) {
+  RenderParams P = P_in;
   const int* rstart = order ? c->region_start : nullptr;        // identity order: the split travels in P.region_start
   int work = P.ncols * P.gy * P.batch;
   int blocks = c->num_cus * OCC;                   // OCC waves per SIMD on every CU
   if (blocks * 4 > work) blocks = (work + 3) / 4;
+  if (P.wave_log && blocks * 4 > WAVE_LOG_WAVES) P.wave_log = nullptr;
+  c->wave_log_waves = P.wave_log ? blocks * 4 : 0;
   dim3 grid((unsigned)blocks), block(256);
   if (traversal_of(c) == DR_TRAVERSAL_WIDE) {
     // the cooperative drain shortens a launch's tail; with many tiles per wave the tail does not show and the leaner build is faster
@@ -1496,7 +1581,7 @@ void feedback_buffers(dr_context* c, const RenderParams& P, int tiles, const int
     c->pixel_cost = nullptr; c->tile_cost = nullptr; c->tile_order = nullptr; c->region_start = nullptr; c->order_capacity = 0; c->order_valid = false;
     if (hipMalloc((void**)&c->pixel_cost, (size_t)tiles * 64 * sizeof(unsigned)) == hipSuccess &&
         hipMalloc((void**)&c->tile_cost, (size_t)tiles * sizeof(unsigned)) == hipSuccess &&
-        hipMalloc((void**)&c->region_start, (MAX_REGIONS + 1) * sizeof(int)) == hipSuccess &&
+        hipMalloc((void**)&c->region_start, (MAX_REGIONS + 2) * sizeof(int)) == hipSuccess &&
         hipMalloc((void**)&c->tile_order, (size_t)tiles * sizeof(int)) == hipSuccess)
       c->order_capacity = tiles;
     else return;
@@ -1528,7 +1613,8 @@ void enqueue_frame(dr_context* c, const RenderParams& P) {
     else launch_persistent_occ<4>(c, P, counter, order, pcost);
     if (pcost) {   // next launch's order from this launch's costs (stream-ordered, no host sync)
       hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);
-      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, c->region_start, tiles, P.regions, c->heavy_factor);
+      hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, c->region_start, tiles, P.regions, c->heavy_factor, c->split_steps,
+                         c->split_parts > 1 ? c->num_cus * (c->occupancy >= 5 ? 5 : 4) * 4 / (2 * c->split_parts) : 0);      // at most half the waves start with a part of a split tile
       c->order_valid = true;
     }
     return;
@@ -1545,6 +1631,18 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "heavy_factor") { if (v < -1 || v > 1000) goto bad; c->heavy_factor = v; c->order_valid = false; }
   else if (name == "coop_steps") { if (v < 0) goto bad; c->coop_steps = v; }
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
+  else if (name == "split_parts") { if (v != 1 && v != 2 && v != 4 && v != 8) goto bad; c->split_parts = v; }
+  else if (name == "split_steps") { if (v < 16 || v > 4080) goto bad; c->split_steps = v & ~15; c->order_valid = false; }
+  else if (name == "coop_rounds") { if (v < 1 || v > 16) goto bad; c->coop_rounds = v; }
+  else if (name == "wave_log") {
+    if (v != 0 && v != 1) goto bad;
+    if (v && !c->wave_log) {
+      const size_t bytes = (size_t)WAVE_LOG_WAVES * 16 * sizeof(unsigned long long) + PIXEL_LOG_WORDS * sizeof(unsigned);
+      if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&c->wave_log, bytes) != hipSuccess) { c->wave_log = nullptr; set_error("cannot allocate the wave log"); return DR_ERR_DEVICE; }
+      (void)hipMemsetAsync(c->wave_log, 0, bytes, c->stream);
+    }
+    c->wave_log_on = v;
+  }
   else if (name == "coop_tiles_per_wave") { if (v < 0) goto bad; c->coop_tiles_per_wave = v; }
   else if (name == "paired") { c->paired = v != 0; }
   else if (name == "roles") { if (v != 0 && v != 3 && v != 6 && v != 7) goto bad; c->roles = v; }
@@ -1664,7 +1762,7 @@ void dr_context_destroy(dr_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* bufs[] = {c->abort_flag, c->paths, c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
+  void* bufs[] = {c->abort_flag, c->wave_log, c->paths, c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -1732,6 +1830,10 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "heavy_factor") *value = c->heavy_factor;
   else if (n == "coop_steps") *value = c->coop_steps;
   else if (n == "coop_lanes") *value = c->coop_lanes;
+  else if (n == "wave_log") *value = c->wave_log_on;
+  else if (n == "coop_rounds") *value = c->coop_rounds;
+  else if (n == "split_parts") *value = c->split_parts;
+  else if (n == "split_steps") *value = c->split_steps;
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
   else if (n == "paired") *value = c->paired;
   else if (n == "roles") *value = c->roles;
@@ -1989,6 +2091,39 @@ int dr_stats_get(dr_context* c, dr_stats* out) {
   if (c->count) out->samples = h[5];
   out->trav_slots = h[6]; out->ray_slots = h[7];
   for (int k = 0; k < 8; k++) out->diag[k] = h[8 + k];
+  return DR_OK;
+}
+
+int dr_stats_wave_log(dr_context* c, unsigned long long* out, int max_waves, int* n_waves) {
+  if (!c || !out || !n_waves || max_waves < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  if (!c->wave_log) { set_error("wave log is off (option wave_log)"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const int n = c->wave_log_waves < max_waves ? c->wave_log_waves : max_waves;
+  if (n > 0) HIP_TRY(hipMemcpy(out, c->wave_log, (size_t)n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  *n_waves = n;
+  return DR_OK;
+}
+
+int dr_stats_pixel_times(dr_context* c, unsigned* out, size_t capacity, size_t* n) {
+  if (!c || !out || !n) { set_error("bad argument"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  size_t m = c->wave_log && c->pixel_cost ? (size_t)2 * c->order_capacity * 64 : 0;
+  if (m > PIXEL_LOG_WORDS || m > capacity) m = 0;
+  if (m > 0) HIP_TRY(hipMemcpy(out, c->wave_log + (size_t)WAVE_LOG_WAVES * 16, m * sizeof(unsigned), hipMemcpyDeviceToHost));
+  *n = m;
+  return DR_OK;
+}
+
+int dr_stats_pixel_cost(dr_context* c, unsigned* out, size_t capacity, size_t* n) {
+  if (!c || !out || !n) { set_error("bad argument"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const size_t have = c->pixel_cost ? (size_t)c->order_capacity * 64 : 0;      // pixel (tile, lane-in-tile) at tile * 64 + lane, tile = block column * gy + block row
+  const size_t m = have < capacity ? have : capacity;
+  if (m > 0) HIP_TRY(hipMemcpy(out, c->pixel_cost, m * sizeof(unsigned), hipMemcpyDeviceToHost));
+  *n = m;
   return DR_OK;
 }
 

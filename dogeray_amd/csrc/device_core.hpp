@@ -9,6 +9,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 // Sensitivity experiments (tools/exp_variant.sh): useless extra work in the wide walk's node step.  All 0 in the product.
+#ifndef DR_WAVE_LOG_DETAIL
+#define DR_WAVE_LOG_DETAIL 0  // experiment builds: the wave log (option wave_log) also counts phases, hand-overs and walking lanes of the drain
+#endif
 #ifndef DR_PAD_VALU
 #define DR_PAD_VALU 0      // n more VALU instructions per node step
 #endif

@@ -109,6 +109,7 @@ struct RenderParams {
   const uint32_t* texels;
   int32_t* out;                   // int32[W*H*3], pixel (x, y) at (x*H + y)*3
   unsigned long long* counters;   // 8 words or null: rays, V, L, S, T, samples, trav_slots, ray_slots
+  unsigned long long* wave_log;   // null, or 16 words per wave of the persistent kernel: begin, queue empty, end (100 MHz ticks), loop iterations after the queue ran empty
   float from[3], llc[3], hor[3], ver[3], uu[3], vu[3];
   float lens_radius;
   float bgint;
@@ -128,6 +129,8 @@ struct RenderParams {
   uint64_t batch_seed_stride;     // frame f of the batch uses seed + f * batch_seed_stride
   int32_t coop_steps;             // drain phase: a ray older than this many node steps is finished cooperatively (0 = never)
   int32_t coop_lanes;             // ... in waves with at most this many lanes still walking
+  int32_t split_parts;            // work-sharing build: parts in which the tiles at the head of the order are handed out (1 = whole)
+  int32_t coop_rounds;            // work sharing: hand-over rounds per loop iteration
   int32_t regions;                // persistent kernel: number of tile queues (1, or 8 = one per XCD)
   int32_t region_start[9];        // identity order: region r owns tiles [region_start[r], region_start[r+1])
 };

@@ -261,6 +261,20 @@ int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the ke
 int dr_stats_reset(dr_context* c);
 int dr_stats_get(dr_context* c, dr_stats* out);
 
+/* Timeline of the last persistent-kernel launch (option "wave_log" = 1 before the launch): sixteen words per wave --
+ * begin, first time the wave found the work queue empty (0: never), end, all in 100 MHz ticks of the GPU's
+ * real-time counter, and the loop iterations the wave ran after the queue was empty (words 4..15: zero, or detail counts of experiment builds).  Shows where a launch's
+ * tail goes (a single frame per launch, K:2154-2224, is mostly tail).  out: 16 * max_waves words. */
+int dr_stats_wave_log(dr_context* c, unsigned long long* out, int max_waves, int* n_waves);
+/* Node steps each pixel of the last frame cost (the persistent kernel's feedback for its tile order, option
+ * "feedback"): pixel (tile, lane) at tile * 64 + lane, tile = block column * ceil(H/8) + block row,
+ * lane = (x & 7) * 8 + (y & 7).  *n = words written (0: no feedback recorded yet). */
+int dr_stats_pixel_cost(dr_context* c, unsigned* out, size_t capacity, size_t* n);
+/* Experiment builds of the library (-DDR_WAVE_LOG_DETAIL=1, option "wave_log" on): 100 MHz ticks since the launch
+ * began at which each pixel of the last single-frame launch was started (first half of out) and finished (second
+ * half), indexed like dr_stats_pixel_cost.  *n = 0 in the product build. */
+int dr_stats_pixel_times(dr_context* c, unsigned* out, size_t capacity, size_t* n);
+
 /* Measurement aid (bench.py `roofline.gather`): rate at which this GPU serves divergent, dependent fetches of 64-byte
  * records from the RESIDENT wide-walk array -- the walk's memory behaviour without its arithmetic.  hot_records
  * restricts the random walk to the first records of the array (0 = all of it). */

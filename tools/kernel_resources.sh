@@ -1,0 +1,16 @@
+#!/bin/bash
+# VGPRs / spills / LDS of every kernel in context.hip (compiles with -save-temps into /tmp/kres): tools/kernel_resources.sh [grep pattern] [extra flags]
+R=$(cd "$(dirname "$0")/.." && pwd)
+rm -rf /tmp/kres && mkdir -p /tmp/kres && cd /tmp/kres
+/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize $2 --offload-arch=gfx950 -c $R/dogeray_amd/csrc/context.hip -o ctx.o -save-temps 2>/dev/null
+python3 - "$1" <<'PY'
+import re, sys
+t = open('/tmp/kres/context-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+pat = sys.argv[1] if len(sys.argv) > 1 else ''
+for m in re.finditer(r'- \.agpr_count:.*?\.wavefront_size:', t, re.S):
+    b = m.group(0)
+    g = lambda k: re.search(r'\.%s:\s*(\S+)' % k, b).group(1)
+    name = g('name')
+    if pat and not re.search(pat, name): continue
+    print("%-90s vgpr %s spill %s sgpr %s lds %s scratch %s" % (name[:90], g('vgpr_count'), g('vgpr_spill_count'), g('sgpr_count'), g('group_segment_fixed_size'), g('private_segment_fixed_size')))
+PY
