@@ -123,9 +123,9 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   int cur_next = 64;               // next unassigned lane-in-tile of cur_tile (64 = exhausted: fetch first)
   int cur_limit = 64;              // ... and where this wave's share of cur_tile ends (split tiles: a part of the tile)
   bool cur_split = false;
-  // tiles at the head of the order that are handed out in P.split_parts parts (work-sharing build, one queue, order from feedback)
+  // tiles at the head of each region's order that are handed out in P.split_parts parts (work-sharing build, order from feedback)
   // (launches of ONE frame: with several frames in the queue the long pixels of one overlap the bulk of the others anyway, and waves that hold cost throughput)
-  const int nsplit = WIDE && COOP && region_start && P.split_parts > 1 && P.regions == 1 && P.batch == 1 ? region_start[MAX_REGIONS + 1] : 0;
+  const bool splitting = WIDE && COOP && region_start && P.split_parts > 1 && P.batch == 1;      // region r's count: region_start[MAX_REGIONS + 1 + r]
   int region = 0, regions_left = P.regions;
   if (P.regions > 1) region = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) % (unsigned)P.regions);   // HW_REG_XCC_ID, 4 bits
   (void)nwork;
@@ -148,7 +148,10 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   // wave lifetime in shader cycles and in 100 MHz ticks, every build: two clock reads per wave, written to the statistics buffer only
   t_begin = __builtin_readcyclecounter(); r_begin = __builtin_amdgcn_s_memrealtime();
   bool held = false;               // COOP: this wave has pixels of a split tile and fetches no new tiles while they live
-  unsigned long long r_empty = 0, n_after = 0;      // wave log (option wave_log): when this wave first found the queue empty, loop iterations since
+  // wave log (option wave_log): when this wave first found the queue empty, loop iterations since.  Only in the build that short launches
+  // use (their timeline is what the log is for): the two scalar instructions per iteration cost the long launches 0.5 %
+  constexpr bool WAVE_LOG = (WIDE && COOP) || DR_WAVE_LOG_DETAIL;
+  unsigned long long r_empty = 0, n_after = 0;
   unsigned long long d_iters = 0;      // loop iterations of the wave
   unsigned long long d_want_give = 0, d_idle = 0, d_owner_walk = 0, d_share_iters = 0, d_wait_owner = 0, d_pending = 0;   // ... of the iterations in which the sharing block ran: givers, idle lanes, walking owners, owners waiting for helpers, lanes waiting for a phase
   unsigned long long d_phases = 0, d_given = 0, d_walking = 0, d_phase_ticks = 0;      // -DDR_WAVE_LOG_DETAIL builds: phases, hand-overs, walking lanes summed, ticks inside phases, all after the queue ran empty
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   for (;;) {
     const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;
-    if (r_empty != 0ull) n_after++;
+    if (WAVE_LOG && r_empty != 0ull) n_after++;
     if (DR_WAVE_LOG_DETAIL) d_iters++;
     if (DR_WAVE_LOG_DETAIL && r_empty != 0ull) d_walking += (unsigned long long)__popcll(__ballot(tr.node >= 0));
     // (a wave that only drains -- queue empty, nobody waiting to be shaded or refilled -- skips the phase: its stash/restore would be
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           want_pixel = true;
         }
       }
-      if (WIDE && COOP && nsplit > 0) {
+      if (WIDE && COOP && splitting) {
         // A wave that took a part of a split tile holds -- fetches no further tile -- while one of those pixels lives: its lanes, as
         // their own pixels end, are helpers that take over subtrees of the long pixels' rays (the work-sharing block below); once
         // the pixels are done the lanes go back to fetching.
@@ -289,6 +292,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
             unsigned t = 0;
             if (lane == 0) t = atomicAdd(tile_counter + region, 1u);
             const int q = (int)__builtin_amdgcn_readfirstlane(t);
+            const int nsplit = splitting ? region_start[MAX_REGIONS + 1 + region] : 0;
             if (q < (r1 - r0 + nsplit * (P.split_parts - 1)) * P.batch) {
               int tt = q / P.batch;
               cur_frame = q - tt * P.batch;
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         }
         if (cur_tile >= ntiles) {                  // frame exhausted: retire the lanes still asking
           if (want_pixel) { tr.node = -3; want_pixel = false; }
-          if (r_empty == 0ull) r_empty = __builtin_amdgcn_s_memrealtime();
+          if (WAVE_LOG && r_empty == 0ull) r_empty = __builtin_amdgcn_s_memrealtime();
           break;
         }
         const int rank = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
@@ -520,7 +524,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
     const unsigned long long r_end = __builtin_amdgcn_s_memrealtime();
     atomicAdd(&P.counters[8], __builtin_readcyclecounter() - t_begin);
     atomicAdd(&P.counters[15], r_end - r_begin);      // 100 MHz ticks: wave cycles / this = shader clock / 100 MHz
-    if (P.wave_log) {
+    if (WAVE_LOG && P.wave_log) {
       unsigned long long* const w = P.wave_log + (size_t)wave_id * 16;
       w[0] = r_begin; w[1] = r_empty; w[2] = r_end; w[3] = n_after; w[4] = d_phases; w[5] = d_given; w[6] = d_walking; w[7] = d_phase_ticks;
       w[8] = d_want_give; w[9] = d_idle; w[10] = d_owner_walk; w[11] = d_share_iters; w[12] = d_wait_owner; w[13] = d_pending; w[14] = d_iters;
@@ -1126,12 +1130,30 @@ __global__ __launch_bounds__(256) void tile_cost_kernel(const unsigned* __restri
 // launch, so they start first; then all other tiles in their natural order, so that the waves of an XCD walk
 // their band coherently (neighbouring tiles see neighbouring parts of the scene).
 constexpr int ORDER_BUCKETS = 256;
+// exclusive prefix sum over the threads of a 1 024-thread block (all of them call it); total = the sum over the block
+__device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned& total) {
+  __shared__ unsigned wave_sum[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  unsigned x = v;
+  for (int off = 1; off < 64; off <<= 1) { const unsigned y = __shfl_up(x, off, 64); if (lane >= off) x += y; }
+  if (lane == 63) wave_sum[w] = x;
+  __syncthreads();
+  if (w == 0) {
+    unsigned sw = lane < 16 ? wave_sum[lane] : 0u;
+    for (int off = 1; off < 16; off <<= 1) { const unsigned y = __shfl_up(sw, off, 64); if (lane >= off) sw += y; }
+    if (lane < 16) wave_sum[lane] = sw;                  // inclusive over the waves
+  }
+  __syncthreads();
+  const unsigned before = w > 0 ? wave_sum[w - 1] : 0u;
+  total = wave_sum[15];
+  __syncthreads();                                       // wave_sum may be reused by the next call
+  return before + x - v;
+}
 __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __restrict__ tile_cost, int* __restrict__ order,
                                                            int* __restrict__ region_start, int ntiles, int regions, int heavy_factor, int split_steps, int split_limit) {
   __shared__ unsigned hist[MAX_REGIONS * ORDER_BUCKETS];   // expensive tiles per (region, cost class)
   __shared__ unsigned base[MAX_REGIONS * ORDER_BUCKETS];
   __shared__ unsigned light_in_region[MAX_REGIONS], light_before[MAX_REGIONS], heavy_in_region[MAX_REGIONS];
-  __shared__ unsigned scan[1024];
   __shared__ unsigned long long total_cost;
   const int nb = regions * ORDER_BUCKETS;
   const int tid = threadIdx.x;
@@ -1139,62 +1161,94 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __rest
   if (tid < MAX_REGIONS) { light_in_region[tid] = 0; heavy_in_region[tid] = 0; }
   if (tid == 0) total_cost = 0;
   __syncthreads();
-  // every thread owns one contiguous chunk of tiles (so that "natural order" is a plain prefix sum)
+  // every thread owns one contiguous chunk of tiles (so that "natural order" is a plain prefix sum); it reads the costs eight at a
+  // time (independent loads: one round trip per eight tiles, three passes) and keeps the region of its current tile as it goes
   const int chunk = (ntiles + (int)blockDim.x - 1) / (int)blockDim.x;
-  const int t0 = tid * chunk, t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
+  const int t0 = tid * chunk < ntiles ? tid * chunk : ntiles, t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
+  auto region_of = [&](int t) { return (int)(((long long)t * regions) / ntiles); };
+  auto region_end = [&](int r) { return (int)(((long long)(r + 1) * ntiles + regions - 1) / regions); };      // first tile of region r + 1
+  auto for_chunk = [&](auto&& body) {
+    int r = t0 < t1 ? region_of(t0) : 0, rend = region_end(r);
+    for (int tb = t0; tb < t1; tb += 8) {
+      unsigned v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[k] = tb + k < t1 ? tile_cost[tb + k] : 0u;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (tb + k < t1) {
+          while (tb + k >= rend) { r++; rend = region_end(r); }
+          body(tb + k, v[k], r);
+        }
+      }
+    }
+  };
   {
     unsigned long long sum = 0;
-    for (int t = t0; t < t1; t++) sum += tile_cost[t];
+    for_chunk([&](int, unsigned cost, int) { sum += cost; });
     atomicAdd(&total_cost, sum);
   }
   __syncthreads();
   const unsigned long long threshold = heavy_factor > 0 ? (total_cost * (unsigned long long)heavy_factor) / (unsigned long long)(ntiles > 0 ? ntiles : 1)
                                                        : (heavy_factor < 0 ? 0ull : ~0ull);       // -1: every tile by cost, 0: all natural
-  auto region_of = [&](int t) { return (int)(((long long)t * regions) / ntiles); };
-  auto heavy = [&](int t) { return (unsigned long long)tile_cost[t] > threshold; };
-  auto key_of = [&](int t) {
-    unsigned b = tile_cost[t] >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
-    return region_of(t) * ORDER_BUCKETS + (ORDER_BUCKETS - 1 - (int)b);      // ascending key = region, then most expensive first
+  auto heavy = [&](unsigned cost) { return (unsigned long long)cost > threshold; };
+  auto key_of = [&](unsigned cost, int r) {
+    unsigned b = cost >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
+    return r * ORDER_BUCKETS + (ORDER_BUCKETS - 1 - (int)b);      // ascending key = region, then most expensive first
   };
-  // tiles whose longest pixel took at least split_steps node steps (a whole cost class: they are a prefix of the order when there is
-  // one region): short launches hand them out in parts (render_persistent_kernel, nsplit)
-  __shared__ unsigned split_tiles;
-  if (tid == 0) split_tiles = 0;
+  // tiles whose longest pixel took at least split_steps node steps (a whole cost class: they are a prefix of their region's order):
+  // launches of one frame hand them out in parts (render_persistent_kernel, nsplit)
+  __shared__ unsigned split_tiles[MAX_REGIONS];
+  if (tid < MAX_REGIONS) split_tiles[tid] = 0;
   __syncthreads();
   unsigned my_light = 0;
-  for (int t = t0; t < t1; t++) {
-    if (heavy(t) && regions == 1 && split_steps > 0 && (tile_cost[t] >> 4) >= (unsigned)(split_steps >> 4)) atomicAdd(&split_tiles, 1u);
-    if (heavy(t)) { atomicAdd(&hist[key_of(t)], 1u); atomicAdd(&heavy_in_region[region_of(t)], 1u); }
-    else { my_light++; atomicAdd(&light_in_region[region_of(t)], 1u); }
+  {
+    // (the light tiles of a region are counted per thread and added once: tens of thousands of atomics on ONE LDS word took 40 us)
+    int cur = -1; unsigned run = 0;
+    for_chunk([&](int, unsigned cost, int r) {
+      if (heavy(cost) && split_steps > 0 && (cost >> 4) >= (unsigned)(split_steps >> 4)) atomicAdd(&split_tiles[r], 1u);
+      if (heavy(cost)) atomicAdd(&hist[key_of(cost, r)], 1u);
+      else {
+        my_light++;
+        if (r != cur) { if (run) atomicAdd(&light_in_region[cur], run); cur = r; run = 0; }
+        run++;
+      }
+    });
+    if (run) atomicAdd(&light_in_region[cur], run);
   }
-  scan[tid] = my_light;
   __syncthreads();
+  // positions: region r's expensive tiles by class, then its light tiles; all prefix sums by the whole block (a single thread
+  // walking the 1 024 + 2 048 counters took 0.1 ms -- per frame when every launch is one frame)
+  unsigned total_light, total_heavy;
+  const unsigned light_rank0 = block_exclusive_scan(my_light, total_light);         // global rank of this thread's first light tile
+  const int i0 = tid * 2;                                                            // nb <= 2 * blockDim.x
+  const unsigned h0 = i0 < nb ? hist[i0] : 0u, h1 = i0 + 1 < nb ? hist[i0 + 1] : 0u;
+  const unsigned heavy_before = block_exclusive_scan(h0 + h1, total_heavy);         // expensive tiles in the classes before i0
   if (tid == 0) {
-    unsigned run = 0;                                   // exclusive scan of the per-thread light counts
-    for (int i = 0; i < (int)blockDim.x; i++) { unsigned v = scan[i]; scan[i] = run; run += v; }
-    unsigned pos = 0, lights = 0;
-    for (int r = 0; r < regions; r++) {
-      region_start[r] = (int)pos;
-      for (int k = 0; k < ORDER_BUCKETS; k++) { base[r * ORDER_BUCKETS + k] = pos; pos += hist[r * ORDER_BUCKETS + k]; }
-      light_before[r] = lights;                         // light tiles in the regions before r
-      heavy_in_region[r] = pos;                         // from here on: where region r's light tiles begin
-      pos += light_in_region[r];
-      lights += light_in_region[r];
-    }
-    region_start[regions] = (int)pos;
-    region_start[MAX_REGIONS + 1] = (int)split_tiles < split_limit ? (int)split_tiles : split_limit;      // (any prefix of the order will do)
+    unsigned lights = 0;
+    for (int r = 0; r < regions; r++) { light_before[r] = lights; lights += light_in_region[r]; }      // light tiles in the regions before r
   }
   __syncthreads();
-  unsigned light_rank = scan[tid];                      // global rank of this thread's first light tile
-  for (int t = t0; t < t1; t++) {
-    if (heavy(t)) {
-      order[atomicAdd(&base[key_of(t)], 1u)] = t;
+  if (i0 < nb) base[i0] = heavy_before + light_before[i0 / ORDER_BUCKETS];
+  if (i0 + 1 < nb) base[i0 + 1] = heavy_before + h0 + light_before[(i0 + 1) / ORDER_BUCKETS];
+  __syncthreads();
+  if (tid < regions) {
+    region_start[tid] = (int)base[tid * ORDER_BUCKETS];
+    const unsigned heavy_through = tid + 1 < regions ? base[(tid + 1) * ORDER_BUCKETS] - light_before[tid + 1] : total_heavy;
+    heavy_in_region[tid] = heavy_through + light_before[tid];                        // where region r's light tiles begin
+    const int limit = split_limit / regions;                                         // (any prefix of a region's order will do)
+    region_start[MAX_REGIONS + 1 + tid] = (int)split_tiles[tid] < limit ? (int)split_tiles[tid] : limit;
+  }
+  if (tid == 0) region_start[regions] = (int)(total_heavy + total_light);
+  __syncthreads();
+  unsigned light_rank = light_rank0;
+  for_chunk([&](int t, unsigned cost, int r) {
+    if (heavy(cost)) {
+      order[atomicAdd(&base[key_of(cost, r)], 1u)] = t;
     } else {
-      const int r = region_of(t);
       order[heavy_in_region[r] + (light_rank - light_before[r])] = t;
       light_rank++;
     }
-  }
+  });
 }
 
 // clamp(acc / divide_by, 0, 255) into row-major RGB8 (draw loop K:2281-2287)
@@ -1349,6 +1403,8 @@ struct dr_context {
   unsigned* pixel_cost = nullptr; unsigned* tile_cost = nullptr; int* tile_order = nullptr; int* region_start = nullptr;
   int order_capacity = 0;          // tiles the three buffers are sized for
   bool order_valid = false;        // tile_order was computed for `order_key`
+  int order_age = 0;               // launches since the view (order_key) changed
+  int feedback_every = 8;          // ... the order is recomputed after the first four of them and then after every feedback_every-th
   float order_key[16] = {0};       // settings13 + W, H, stripe of the frame the order belongs to
   bool feedback = true;
   int stripe_mod = 1, stripe_rem = 0;
@@ -1367,6 +1423,7 @@ struct dr_context {
   int coop_lanes = 8;       // ... in waves with at most this many lanes still walking
   int split_parts = 8;      // short launches: the tiles with last frame's longest pixels are handed out in this many parts (1, 2, 4, 8), the rest of each wave helps
   int split_steps = 400;    // ... tiles whose longest pixel took at least this many node steps (multiple of 16)
+  int short_one_queue = 1;  // short launches use one tile queue instead of one per XCD
   int coop_rounds = 2;      // work sharing: hand-over rounds per loop iteration
   int wave_log_on = 0;      // persistent kernel writes begin / queue-empty / end stamps of every wave (dr_stats_wave_log)
   unsigned long long* wave_log = nullptr; int wave_log_waves = 0;
@@ -1473,7 +1530,7 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
     if (tiles < 64 * MAX_REGIONS) P.regions = 1;                 // tiny frames: one queue
     // a short launch (few tiles per wave: one frame, or a thin stripe of a few) ends when its slowest band ends; one queue
     // balances better there than eight (1.88 instead of 2.00 ms for a single 1920x1080 frame of the bench scene)
-    if ((long long)tiles * batch_hint < (long long)c->coop_tiles_per_wave * c->num_cus * 20) P.regions = 1;
+    if (c->short_one_queue && (long long)tiles * batch_hint < (long long)c->coop_tiles_per_wave * c->num_cus * 20) P.regions = 1;
     for (int r = 0; r <= MAX_REGIONS; r++) P.region_start[r] = r <= P.regions ? (int)(((long long)tiles * r + P.regions - 1) / P.regions) : tiles;
   }
   return DR_OK;
@@ -1538,6 +1595,7 @@ void launch_persistent(dr_context* c, const RenderParams& P_in, unsigned* counte
   if (traversal_of(c) == DR_TRAVERSAL_WIDE) {
     // the cooperative drain shortens a launch's tail; with many tiles per wave the tail does not show and the leaner build is faster
     const bool coop = P.coop_steps > 0 && (long long)work < (long long)c->coop_tiles_per_wave * blocks * 4;
+    if (!coop && !DR_WAVE_LOG_DETAIL) c->wave_log_waves = 0;      // only the work-sharing build writes the log
     const bool degenerate = P.max_depth <= 0 || !(P.spp_f > 0.0f);
     if (c->paired && !c->count && !coop && !degenerate && OCC == 5 && ensure_paths(c, (size_t)blocks * 4)) {
       // long launch: two paths per lane
@@ -1581,7 +1639,7 @@ void feedback_buffers(dr_context* c, const RenderParams& P, int tiles, const int
     c->pixel_cost = nullptr; c->tile_cost = nullptr; c->tile_order = nullptr; c->region_start = nullptr; c->order_capacity = 0; c->order_valid = false;
     if (hipMalloc((void**)&c->pixel_cost, (size_t)tiles * 64 * sizeof(unsigned)) == hipSuccess &&
         hipMalloc((void**)&c->tile_cost, (size_t)tiles * sizeof(unsigned)) == hipSuccess &&
-        hipMalloc((void**)&c->region_start, (MAX_REGIONS + 2) * sizeof(int)) == hipSuccess &&
+        hipMalloc((void**)&c->region_start, (2 * MAX_REGIONS + 1) * sizeof(int)) == hipSuccess &&
         hipMalloc((void**)&c->tile_order, (size_t)tiles * sizeof(int)) == hipSuccess)
       c->order_capacity = tiles;
     else return;
@@ -1611,12 +1669,17 @@ void enqueue_frame(dr_context* c, const RenderParams& P) {
     feedback_buffers(c, P, tiles, order, pcost);
     if (c->occupancy >= 5) launch_persistent_occ<5>(c, P, counter, order, pcost);
     else launch_persistent_occ<4>(c, P, counter, order, pcost);
-    if (pcost) {   // next launch's order from this launch's costs (stream-ordered, no host sync)
+    // next launch's order from this launch's costs (stream-ordered, no host sync).  The view does not change between the frames of
+    // a progressive render, so after the first few launches of a view the order is refreshed every feedback_every-th launch only
+    // (the two kernels take 75 us: nothing for a launch of 32 frames, 6 % of a launch of one)
+    if (pcost && !c->order_valid) c->order_age = 0;
+    if (pcost && (c->order_age < 4 || c->order_age % c->feedback_every == 0)) {
       hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);
       hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, c->region_start, tiles, P.regions, c->heavy_factor, c->split_steps,
                          c->split_parts > 1 ? c->num_cus * (c->occupancy >= 5 ? 5 : 4) * 4 / (2 * c->split_parts) : 0);      // at most half the waves start with a part of a split tile
       c->order_valid = true;
     }
+    c->order_age++;
     return;
   }
   if (c->occupancy >= 6) launch_tile<6>(c, P);
@@ -1633,6 +1696,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
   else if (name == "split_parts") { if (v != 1 && v != 2 && v != 4 && v != 8) goto bad; c->split_parts = v; }
   else if (name == "split_steps") { if (v < 16 || v > 4080) goto bad; c->split_steps = v & ~15; c->order_valid = false; }
+  else if (name == "short_one_queue") { c->short_one_queue = v != 0; c->order_valid = false; }
   else if (name == "coop_rounds") { if (v < 1 || v > 16) goto bad; c->coop_rounds = v; }
   else if (name == "wave_log") {
     if (v != 0 && v != 1) goto bad;
@@ -1651,6 +1715,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
+  else if (name == "feedback_every") { if (v < 1) goto bad; c->feedback_every = v; }
   else if (name == "wide_tree") { if (v != 0 && v != 1) goto bad; c->wide_tree = v; }      // takes effect at the next dr_context_upload_scene
   else { set_error("unknown option '" + name + "'"); return DR_ERR_INVALID; }
   return DR_OK;
@@ -1822,6 +1887,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   if (n == "kernel") *value = c->kernel;
   else if (n == "batch_frames") *value = c->batch_frames;
   else if (n == "feedback") *value = c->feedback ? 1 : 0;
+  else if (n == "feedback_every") *value = c->feedback_every;
   else if (n == "occupancy") *value = c->occupancy;
   else if (n == "trav_min") *value = c->trav_min;
   else if (n == "park_min") *value = c->park_min;
@@ -1832,6 +1898,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_lanes") *value = c->coop_lanes;
   else if (n == "wave_log") *value = c->wave_log_on;
   else if (n == "coop_rounds") *value = c->coop_rounds;
+  else if (n == "short_one_queue") *value = c->short_one_queue;
   else if (n == "split_parts") *value = c->split_parts;
   else if (n == "split_steps") *value = c->split_steps;
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;

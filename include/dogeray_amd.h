@@ -261,7 +261,8 @@ int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the ke
 int dr_stats_reset(dr_context* c);
 int dr_stats_get(dr_context* c, dr_stats* out);
 
-/* Timeline of the last persistent-kernel launch (option "wave_log" = 1 before the launch): sixteen words per wave --
+/* Timeline of the last SHORT persistent-kernel launch (fewer than coop_tiles_per_wave tiles per wave: one frame, a thin stripe;
+ * option "wave_log" = 1 before the launch): sixteen words per wave --
  * begin, first time the wave found the work queue empty (0: never), end, all in 100 MHz ticks of the GPU's
  * real-time counter, and the loop iterations the wave ran after the queue was empty (words 4..15: zero, or detail counts of experiment builds).  Shows where a launch's
  * tail goes (a single frame per launch, K:2154-2224, is mostly tail).  out: 16 * max_waves words. */
