@@ -153,6 +153,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   constexpr bool WAVE_LOG = (WIDE && COOP) || DR_WAVE_LOG_DETAIL;
   unsigned long long r_empty = 0, n_after = 0;
   unsigned long long d_iters = 0;      // loop iterations of the wave
+  unsigned long long d_home_tiles = 0, d_stolen_tiles = 0, d_left_home = 0;      // (tools/exp_regions.py) tiles from the region the wave began in / from others, when it left the first
+  const int d_home = region;
   unsigned long long d_want_give = 0, d_idle = 0, d_owner_walk = 0, d_share_iters = 0, d_wait_owner = 0, d_pending = 0;   // ... of the iterations in which the sharing block ran: givers, idle lanes, walking owners, owners waiting for helpers, lanes waiting for a phase
   unsigned long long d_phases = 0, d_given = 0, d_walking = 0, d_phase_ticks = 0;      // -DDR_WAVE_LOG_DETAIL builds: phases, hand-overs, walking lanes summed, ticks inside phases, all after the queue ran empty
   ParkedLeaf pk; pk.v0x = 0; pk.C = pk.D = u32x4{0, 0, 0, 0}; pk.info = 0; pk.parked = false;   // PARK_MIN > 0 only
@@ -307,8 +309,10 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
                 tt -= nsplit * (P.split_parts - 1);
               }
               cur_tile = tile_order ? tile_order[r0 + tt] : r0 + tt;
+              if (DR_WAVE_LOG_DETAIL) { if (region == d_home) d_home_tiles++; else d_stolen_tiles++; }
               break;
             }
+            if (DR_WAVE_LOG_DETAIL && region == d_home && d_left_home == 0ull) d_left_home = __builtin_amdgcn_s_memrealtime();
             region = region + 1 == P.regions ? 0 : region + 1;   // this band is done: help with the next one
             regions_left--;
           }
@@ -528,6 +532,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       unsigned long long* const w = P.wave_log + (size_t)wave_id * 16;
       w[0] = r_begin; w[1] = r_empty; w[2] = r_end; w[3] = n_after; w[4] = d_phases; w[5] = d_given; w[6] = d_walking; w[7] = d_phase_ticks;
       w[8] = d_want_give; w[9] = d_idle; w[10] = d_owner_walk; w[11] = d_share_iters; w[12] = d_wait_owner; w[13] = d_pending; w[14] = d_iters;
+      if (DR_WAVE_LOG_DETAIL) { w[4] = d_home_tiles; w[5] = d_stolen_tiles; w[6] = d_left_home; w[15] = (unsigned long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u); }
     }
   }
   if (COUNT && lane == 0) {
