@@ -6,7 +6,7 @@ TAG=${1:-r1}; shift
 OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-ARGS="--steps 32 --warmup 32 --repeats 1 --no-cpu-baseline --no-traffic --no-extras $@"
+ARGS="--steps 32 --warmup 64 --repeats 5 --no-cpu-baseline --no-traffic --no-extras $@"
 python3 bench.py $ARGS > $OUT/bench_plain.json 2> $OUT/bench_plain.err || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o trace --output-format csv -- python3 bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/trace.err || { tail -5 $OUT/trace.err; exit 1; }
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU -d $OUT/pmc1 -o pmc --output-format csv -- python3 bench.py $ARGS > /dev/null 2> $OUT/pmc1.err || { tail -5 $OUT/pmc1.err; exit 1; }
