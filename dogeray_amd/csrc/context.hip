@@ -1409,8 +1409,9 @@ struct dr_context {
   int order_capacity = 0;          // tiles the three buffers are sized for
   bool order_valid = false;        // tile_order was computed for `order_key`
   int order_age = 0;               // launches since the view (order_key) changed
+  int order_follows_camera = 1;    // a view with the same frame geometry but other settings starts from the previous view's tile order
   int feedback_every = 8;          // ... the order is recomputed after the first four of them and then after every feedback_every-th
-  float order_key[16] = {0};       // settings13 + W, H, stripe of the frame the order belongs to
+  float order_key[18] = {0};       // settings13 + W, H, stripe, tile grid of the frame the order belongs to
   bool feedback = true;
   int stripe_mod = 1, stripe_rem = 0;
   int traversal = DR_TRAVERSAL_WIDE;
@@ -1650,11 +1651,18 @@ void feedback_buffers(dr_context* c, const RenderParams& P, int tiles, const int
     else return;
   }
   // the stored order belongs to one view: same settings, size and stripe (progressive frames)
-  float key[16] = {0};
+  float key[18] = {0};
   memcpy(key, c->cur_settings, 13 * sizeof(float));
   key[13] = (float)P.W; key[14] = (float)P.H; key[15] = (float)(P.stripe_mod * 1024 + P.stripe_rem) + 0.125f * (float)P.regions;
+  key[16] = (float)P.ncols; key[17] = (float)P.gy;      // the tile grid (the preview divisor settings[11] changes it with W and H unchanged)
   if (c->order_valid && memcmp(c->order_key, key, sizeof(key)) == 0) order = c->tile_order;
-  else { memcpy(c->order_key, key, sizeof(key)); c->order_valid = false; }
+  else if (c->order_valid && c->order_follows_camera && memcmp(c->order_key + 13, key + 13, 5 * sizeof(float)) == 0) {
+    // same frame geometry, other camera / depth / samples (an interactive viewer moving the camera, K:2341-2500: every frame is a new
+    // view): the last view's costs are a better guess than none -- any order is a valid order -- and they are refreshed at once
+    order = c->tile_order;
+    memcpy(c->order_key, key, sizeof(key));
+    c->order_age = 0;
+  } else { memcpy(c->order_key, key, sizeof(key)); c->order_valid = false; }
   pcost = c->pixel_cost;
 }
 
@@ -1677,7 +1685,7 @@ void enqueue_frame(dr_context* c, const RenderParams& P) {
     // next launch's order from this launch's costs (stream-ordered, no host sync).  The view does not change between the frames of
     // a progressive render, so after the first few launches of a view the order is refreshed every feedback_every-th launch only
     // (the two kernels take 75 us: nothing for a launch of 32 frames, 6 % of a launch of one)
-    if (pcost && !c->order_valid) c->order_age = 0;
+    if (pcost && !order) c->order_age = 0;
     if (pcost && (c->order_age < 4 || c->order_age % c->feedback_every == 0)) {
       hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);
       hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, c->region_start, tiles, P.regions, c->heavy_factor, c->split_steps,
@@ -1720,6 +1728,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
+  else if (name == "order_follows_camera") { c->order_follows_camera = v != 0; }
   else if (name == "feedback_every") { if (v < 1) goto bad; c->feedback_every = v; }
   else if (name == "wide_tree") { if (v != 0 && v != 1) goto bad; c->wide_tree = v; }      // takes effect at the next dr_context_upload_scene
   else { set_error("unknown option '" + name + "'"); return DR_ERR_INVALID; }
@@ -1893,6 +1902,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "batch_frames") *value = c->batch_frames;
   else if (n == "feedback") *value = c->feedback ? 1 : 0;
   else if (n == "feedback_every") *value = c->feedback_every;
+  else if (n == "order_follows_camera") *value = c->order_follows_camera;
   else if (n == "occupancy") *value = c->occupancy;
   else if (n == "trav_min") *value = c->trav_min;
   else if (n == "park_min") *value = c->park_min;

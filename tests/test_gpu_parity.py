@@ -249,6 +249,25 @@ def test_progressive_accumulation(dr, orc, ctx, tmp_path):
         assert np.array_equal(img, want.transpose(1, 0, 2))
 
 
+def test_moving_camera_keeps_the_previous_views_tile_order(dr, orc, ctx, synth):
+    """An interactive viewer changes the camera between frames (K:2341-2500: every frame is a new view).  The persistent kernel then starts
+    from the previous view's tile order (same tile grid: any order is a valid order) instead of none -- frames identical to the oracle's,
+    also when the preview divisor changes the tile grid with W and H unchanged (that must NOT reuse the order)."""
+    path = os.path.join(synth["dir"], "hf_small.rts")
+    ps, os_ = _load_both(dr, orc, path, "")
+    ctx.upload(ps)
+    s = ps.settings()
+    W, H = 320, 192
+    assert ctx.get_option("order_follows_camera") == 1
+    for k, (dx, div, depth) in enumerate([(0.0, 1, None), (0.0, 1, None), (0.4, 1, None), (0.8, 1, 3), (0.8, 2, 3), (1.2, 2, None), (1.2, 1, None), (-2.0, 1, None)]):
+        st = dr.pack_settings13(s, div, spp=1, depth=depth)
+        st[0] += dx
+        st[4] -= 0.5 * dx
+        g = ctx.render_frame(st, W, H, s.background, 77 + k)
+        r, _ = os_.render(st, W, H, s.background, 77 + k, nthreads=4)
+        _assert_frames(g, r, "moving camera, frame %d" % k)
+
+
 def test_stripes_partition_the_frame(dr, ctx, synth):
     """Multi-GPU partition: block columns bx % R == r; the union over r is the 1-GPU frame."""
     ps = dr.Scene.load(os.path.join(synth["dir"], "hf_small.rts"))

@@ -20,9 +20,16 @@ for opts in (sys.argv[1:] or [""]):
     ctx.accum_reset(W, H)
     ctx.render_accumulate(st, W, H, s.background, 1, 1000003, n)
     best = None
+    move = float(os.environ.get("MOVE", "0"))       # MOVE=0.05: the camera moves by that much between frames (every frame is a new view)
     for rep in range(3):
         ctx.stats_reset()
-        ctx.render_accumulate(st, W, H, s.background, 1, 1000003, n)
+        if move:
+            for k in range(n):
+                st2 = st.copy(); st2[0] += move * (k + 1 + n * rep)
+                ctx.accum_reset(W, H)
+                ctx.render_accumulate(st2, W, H, s.background, 1 + k, 1000003, 1)
+        else:
+            ctx.render_accumulate(st, W, H, s.background, 1, 1000003, n)
         o = ctx.stats()
         ms = o["kernel_ms"] / max(1, o["launches"])
         if best is None or ms < best[0]: best = (ms, o)
