@@ -1427,7 +1427,8 @@ struct dr_context {
   int coop_steps = 2;       // persistent kernel, drain phase: rays older than this many steps are shared with idle lanes / finished cooperatively (0 = off)
   int coop_tiles_per_wave = 32;   // wide walk: launches with fewer tiles per wave than this run the build with the work-sharing drain
   int coop_lanes = 8;       // ... in waves with at most this many lanes still walking
-  int split_parts = 8;      // short launches: the tiles with last frame's longest pixels are handed out in this many parts (1, 2, 4, 8), the rest of each wave helps
+  int split_parts = 4;      // short launches: the tiles with last frame's longest pixels are handed out in this many parts (1, 2, 4, 8), the rest of each wave helps
+  int split_waves = 12;     // ... as many of them as give this many percent of the waves a part to start with
   int split_steps = 400;    // ... tiles whose longest pixel took at least this many node steps (multiple of 16)
   int short_one_queue = 1;  // short launches use one tile queue instead of one per XCD
   int coop_rounds = 2;      // work sharing: hand-over rounds per loop iteration
@@ -1689,7 +1690,7 @@ void enqueue_frame(dr_context* c, const RenderParams& P) {
     if (pcost && (c->order_age < 4 || c->order_age % c->feedback_every == 0)) {
       hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);
       hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, c->region_start, tiles, P.regions, c->heavy_factor, c->split_steps,
-                         c->split_parts > 1 ? c->num_cus * (c->occupancy >= 5 ? 5 : 4) * 4 / (2 * c->split_parts) : 0);      // at most half the waves start with a part of a split tile
+                         c->split_parts > 1 ? (int)((long long)c->num_cus * (c->occupancy >= 5 ? 5 : 4) * 4 * c->split_waves / (100 * c->split_parts)) : 0);      // at most split_waves % of the waves start with a part of a split tile
       c->order_valid = true;
     }
     c->order_age++;
@@ -1708,6 +1709,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "coop_steps") { if (v < 0) goto bad; c->coop_steps = v; }
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
   else if (name == "split_parts") { if (v != 1 && v != 2 && v != 4 && v != 8) goto bad; c->split_parts = v; }
+  else if (name == "split_waves") { if (v < 1 || v > 1000) goto bad; c->split_waves = v; c->order_valid = false; }
   else if (name == "split_steps") { if (v < 16 || v > 4080) goto bad; c->split_steps = v & ~15; c->order_valid = false; }
   else if (name == "short_one_queue") { c->short_one_queue = v != 0; c->order_valid = false; }
   else if (name == "coop_rounds") { if (v < 1 || v > 16) goto bad; c->coop_rounds = v; }
@@ -1916,6 +1918,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "short_one_queue") *value = c->short_one_queue;
   else if (n == "split_parts") *value = c->split_parts;
   else if (n == "split_steps") *value = c->split_steps;
+  else if (n == "split_waves") *value = c->split_waves;
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
   else if (n == "paired") *value = c->paired;
   else if (n == "roles") *value = c->roles;

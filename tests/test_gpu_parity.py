@@ -326,7 +326,8 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
               {"kernel": 1, "trav_min": 32, "park_min": 8, "unroll": 1}, {"kernel": 1, "unroll": 3}, {"kernel": 1, "park_min": 16, "unroll": 2},
               {"kernel": 1, "batch_frames": 1, "coop_steps": 1, "coop_lanes": 64}, {"kernel": 1, "batch_frames": 1, "coop_steps": 0},
               {"kernel": 1, "batch_frames": 2, "coop_steps": 16, "coop_lanes": 4},
-              {"kernel": 1, "batch_frames": 1, "split_parts": 4, "split_steps": 32, "coop_rounds": 4}, {"kernel": 1, "batch_frames": 3, "split_parts": 8, "split_steps": 16},
+              {"kernel": 1, "batch_frames": 1, "split_parts": 4, "split_steps": 32, "coop_rounds": 4, "split_waves": 50}, {"kernel": 1, "batch_frames": 3, "split_parts": 8, "split_steps": 16},
+              {"kernel": 1, "batch_frames": 1, "split_parts": 8, "split_steps": 16, "split_waves": 400},
               {"kernel": 1, "batch_frames": 1, "split_parts": 1, "coop_rounds": 1},
               {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 48},       # two paths per lane
               {"kernel": 1, "batch_frames": 4, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 32},
@@ -344,7 +345,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
             base = acc
         assert np.array_equal(acc, base), opts
     for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 16, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 2, "coop_lanes": 8, "coop_rounds": 2,
-                 "split_parts": 8, "split_steps": 400, "coop_tiles_per_wave": 32, "paired": 0, "roles": 0}.items():
+                 "split_parts": 4, "split_steps": 400, "split_waves": 12, "coop_tiles_per_wave": 32, "paired": 0, "roles": 0}.items():
         ctx.set_option(k, v)
     assert ctx.get_option("park_min") == 16 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
     with pytest.raises(dr.DogerayError):
@@ -571,13 +572,13 @@ def test_work_sharing_drain_renders_like_the_oracle(dr, orc, ctx, synth, tmp_pat
     cases = [(random_scene(rng, int(rng.integers(50, 900)), str(tmp_path / ("share%d.rts" % k)), W=96, H=64, textures=names), synth["tex"], 96, 64) for k in range(6)]
     cases += [(os.path.join(SCENES, "scene.rts"), "", 320, 192), (os.path.join(synth["dir"], "hf_small.rts"), "", 320, 192),
               (os.path.join(synth["dir"], "city_small.rts"), "", 200, 120)]
-    defaults = {k: ctx.get_option(k) for k in ("coop_steps", "coop_lanes", "coop_rounds", "split_parts", "split_steps")}
+    defaults = {k: ctx.get_option(k) for k in ("coop_steps", "coop_lanes", "coop_rounds", "split_parts", "split_steps", "split_waves")}
     # split_parts / split_steps: tiles whose longest pixel took split_steps node steps in the previous frame are handed out in parts and
     # the rest of each wave helps from the start; _render_pair renders every frame twice (the second launch has the first one's costs),
     # so the split path runs
     combos = ({"coop_steps": 1, "coop_lanes": 64, "split_parts": 1}, {"coop_steps": 4, "coop_rounds": 1, "split_parts": 1}, {"coop_steps": 8, "coop_rounds": 4},
               {"coop_steps": 1, "split_parts": 4, "split_steps": 16, "coop_rounds": 3}, {"coop_steps": 2, "split_parts": 2, "split_steps": 32},
-              {"split_parts": 8, "split_steps": 16}, {"split_parts": 8, "split_steps": 64, "coop_steps": 1, "coop_rounds": 16})
+              {"split_parts": 8, "split_steps": 16, "split_waves": 50}, {"split_parts": 8, "split_steps": 64, "coop_steps": 1, "coop_rounds": 16, "split_waves": 1000})
     for combo in combos:
         for k, v in combo.items():
             ctx.set_option(k, v)

@@ -6,8 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 import dogeray_amd as dr
 W, H = 1920, 1080
-path = bench.ensure_scene(os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"), 709, W, H)
-sc = dr.Scene.load(path, ""); sc.build_bvh(); s = sc.settings()
+if os.environ.get("SCENE"):          # SCENE=/tmp/cfg/bunny.rts [TEX=/tmp/cfg/tex]: another scene at its own size (tools/r2_configs.sh generates them)
+    path = os.environ["SCENE"]
+    sc = dr.Scene.load(path, os.environ.get("TEX", "")); sc.build_bvh(); s = sc.settings()
+    W, H = s.width, s.height
+else:
+    path = bench.ensure_scene(os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"), 709, W, H)
+    sc = dr.Scene.load(path, ""); sc.build_bvh(); s = sc.settings()
 ctx = dr.Context(0).upload(sc)
 st = dr.pack_settings13(s, 1, spp=1)
 n = int(os.environ.get("FRAMES", "16"))
@@ -36,6 +41,6 @@ for opts in (sys.argv[1:] or [""]):
     ms, o = best
     d = o["diag"]
     clk = 1e8 * d[0] / max(1, d[7])
-    life = d[0] / max(1, o["launches"]) / 5120 / clk * 1e3
+    life = d[0] / max(1, o["launches"]) / 5120 / clk * 1e3      # (5120 waves: right for frames of 5120+ tiles)
     print("%-40s %.4f ms/launch (%d launches, %d frames)  mean wave lifetime %.4f ms = %.0f%%  clock %.0f MHz" % (opts or "(defaults)", ms, o["launches"], o["frames"], life, 100 * life / ms, clk / 1e6))
     for k, v in old.items(): ctx.set_option(k, v)

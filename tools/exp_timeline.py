@@ -9,8 +9,12 @@ import dogeray_amd as dr
 W, H = 1920, 1080
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 opts = sys.argv[2] if len(sys.argv) > 2 else ""
-path = bench.ensure_scene(os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"), 709, W, H)
-sc = dr.Scene.load(path, ""); sc.build_bvh(); s = sc.settings()
+if os.environ.get("SCENE"):          # another scene at its own size
+    sc = dr.Scene.load(os.environ["SCENE"], os.environ.get("TEX", "")); sc.build_bvh(); s = sc.settings()
+    W, H = s.width, s.height
+else:
+    path = bench.ensure_scene(os.environ.get("DOGERAY_BENCH_CACHE", "/tmp/dogeray_bench"), 709, W, H)
+    sc = dr.Scene.load(path, ""); sc.build_bvh(); s = sc.settings()
 ctx = dr.Context(0).upload(sc)
 for kv in opts.split(","):
     if kv: ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
@@ -77,6 +81,6 @@ if pt is not None and pc.size:
     for i in last:
         x, y = np.unravel_index(i, pe.shape)
         print("   pixel (%4d,%4d): steps %4d  started %7.1f  finished %7.1f us  (%.2f us/step)" % (x, y, pc[x, y], ps[x, y], pe[x, y], life[x, y] / max(1, pc[x, y])))
-    for spec in os.environ.get("PIXELS", "1103,623;1099,620;1099,623;1110,621;1037,623").split(";"):
+    for spec in os.environ.get("PIXELS", "1103,623;1099,620;1099,623;1110,621;1037,623" if not os.environ.get("SCENE") else "0,0").split(";"):
         x, y = map(int, spec.split(","))
         print("   watched pixel (%4d,%4d): steps %4d  started %7.1f  finished %7.1f us  (%.2f us/step)" % (x, y, pc[x, y], ps[x, y], pe[x, y], life[x, y] / max(1, pc[x, y])))
