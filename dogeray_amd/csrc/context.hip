@@ -198,11 +198,13 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
       float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? WIDE_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
       if (WIDE) {
-        st[0 * 64] = __uint_as_float(ws.top); st[1 * 64] = __int_as_float(ws.sp);
+        // ten words (26 KiB of LDS per workgroup with the stack: six workgroups per CU): the stack pointer shares a word with the frame
+        // of the batch, x + 1 (0: no pixel) with y -- make_params bounds the frame size
+        st[0 * 64] = __uint_as_float(ws.top); st[1 * 64] = __int_as_float(ws.sp | (frame << 8));
         st[2 * 64] = color.x; st[3 * 64] = color.y; st[4 * 64] = color.z;
-        st[5 * 64] = __int_as_float(px); st[6 * 64] = __int_as_float(py); st[7 * 64] = __int_as_float(pcode);
-        st[8 * 64] = __int_as_float(frame); st[9 * 64] = __int_as_float(sample);
-        st[10 * 64] = __uint_as_float(steps); st[11 * 64] = __uint_as_float(rstart);
+        st[5 * 64] = __int_as_float(((px + 1) << 16) | py); st[6 * 64] = __int_as_float(pcode);
+        st[7 * 64] = __int_as_float(sample);
+        st[8 * 64] = __uint_as_float(steps); st[9 * 64] = __uint_as_float(rstart);
         asm volatile("" ::: "memory");
       } else {
         st[0 * 64] = pk.v0x; st[1 * 64] = __uint_as_float(pk.C.x); st[2 * 64] = __uint_as_float(pk.C.y); st[3 * 64] = __uint_as_float(pk.C.z); st[4 * 64] = __uint_as_float(pk.C.w);
@@ -234,9 +236,10 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (WIDE) {
         asm volatile("" ::: "memory");
         color = mk(st[2 * 64], st[3 * 64], st[4 * 64]);
-        px = __float_as_int(st[5 * 64]); py = __float_as_int(st[6 * 64]); pcode = __float_as_int(st[7 * 64]);
-        frame = __float_as_int(st[8 * 64]); sample = __float_as_int(st[9 * 64]);
-        steps = __float_as_uint(st[10 * 64]); rstart = __float_as_uint(st[11 * 64]);
+        { const int xy = __float_as_int(st[5 * 64]); px = (int)((unsigned)xy >> 16) - 1; py = xy & 0xffff; }
+        pcode = __float_as_int(st[6 * 64]);
+        frame = __float_as_int(st[1 * 64]) >> 8; sample = __float_as_int(st[7 * 64]);
+        steps = __float_as_uint(st[8 * 64]); rstart = __float_as_uint(st[9 * 64]);
       } else {
         asm volatile("" ::: "memory");
         color = mk(st[14 * 64], st[15 * 64], st[16 * 64]);
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
       if (WIDE) {
         asm volatile("" ::: "memory");
-        ws.top = __float_as_uint(st[0 * 64]); ws.sp = __float_as_int(st[1 * 64]);
+        ws.top = __float_as_uint(st[0 * 64]); ws.sp = __float_as_int(st[1 * 64]) & 0xff;
         if (fresh_ray) { ws.top = 0u; ws.sp = 0; ws.sb = 0; }
         inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);      // 1/direction and the folded test's margins are
         wr = wide_ray(path.rayo, inv, P.wide_pmax);                                        // recomputed for every lane rather than stashed
@@ -1418,7 +1421,7 @@ struct dr_context {
   bool count = false;
   // tunables (dr_context_set_option / DOGERAY_OPTIONS)
   int kernel = DR_KERNEL_PERSISTENT;
-  int occupancy = 5;        // waves per SIMD the kernel is built and launched for (persistent: 4 or 5; tile kernel: 4 or 6)
+  int occupancy = 6;        // waves per SIMD the kernel is built and launched for (persistent: 4, 5, or 6 = six for the lean wide build and five for the others; tile kernel: 4 or 6)
   int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
   int park_min = 16;        // persistent kernel: leaf steps (parked leaves) once this many lanes stand at one (0 = on the spot)
   int unroll = 2;           // persistent kernel: node steps per loop iteration
@@ -1488,7 +1491,7 @@ inline int hf2i(float f) {
 // host (it is identical for every pixel) with the reference's float/double promotions.
 int make_params(dr_context* c, const float* st, int W, int H, float background, uint64_t seed, RenderParams& P, int batch_hint = 1) {
   if (!c->walk) { set_error("no scene uploaded"); return DR_ERR_INVALID; }
-  if (W <= 0 || H <= 0 || (size_t)W * (size_t)H > (size_t)1 << 28) { set_error("bad frame size"); return DR_ERR_INVALID; }
+  if (W <= 0 || H <= 0 || W > 65000 || H > 65000 || (size_t)W * (size_t)H > (size_t)1 << 28) { set_error("bad frame size"); return DR_ERR_INVALID; }      // (x and y share a word in the phase stash)
   const int div = hf2i(st[11]);
   if (div < 1) { set_error("divisor must be >= 1"); return DR_ERR_INVALID; }
   const int backtex = hf2i(st[12]);
@@ -1620,6 +1623,21 @@ void launch_persistent(dr_context* c, const RenderParams& P_in, unsigned* counte
   else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, false>), grid, block, 0, c->stream, P, counter, order, rstart, pixel_cost);
 }
 
+// Six waves per SIMD (occupancy 6): only the wide walk's lean build fits -- 80 VGPRs and 26 KiB of LDS per workgroup -- and only with the
+// default thresholds; every other launch (counting build, work-sharing build of short launches, other tunings) runs five.
+bool launch_wide_lean6(dr_context* c, const RenderParams& P_in, unsigned* counter, const int* order, unsigned* pixel_cost) {
+  if (traversal_of(c) != DR_TRAVERSAL_WIDE || c->count || c->paired || c->trav_min != 32 || c->park_min != 16 || c->unroll != 2) return false;
+  RenderParams P = P_in;
+  const long long work = (long long)P.ncols * P.gy * P.batch;
+  if (P.coop_steps > 0 && work < (long long)c->coop_tiles_per_wave * c->num_cus * 5 * 4) return false;      // a short launch: work-sharing build
+  int blocks = c->num_cus * 6;
+  if ((long long)blocks * 4 > work) blocks = (int)((work + 3) / 4);
+  P.wave_log = nullptr; c->wave_log_waves = 0;
+  hipLaunchKernelGGL((render_persistent_kernel<false, 6, 32, 16, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, c->stream, P, counter, order,
+                     order ? c->region_start : nullptr, pixel_cost);
+  return true;
+}
+
 // The instantiated tunings; dr_context_set_option only accepts these values.
 template <int OCC>
 void launch_persistent_occ(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pcost) {
@@ -1681,7 +1699,8 @@ void enqueue_frame(dr_context* c, const RenderParams& P) {
         (long long)tiles * P.batch >= (long long)c->coop_tiles_per_wave * c->num_cus * 20 && (c->roles == 7 ? launch_roles<7, 1>(c, P, counter) : (c->roles == 6 ? launch_roles<6, 2>(c, P, counter) : launch_roles<3, 1>(c, P, counter)))) return;
     const int* order; unsigned* pcost;
     feedback_buffers(c, P, tiles, order, pcost);
-    if (c->occupancy >= 5) launch_persistent_occ<5>(c, P, counter, order, pcost);
+    if (c->occupancy >= 6 && launch_wide_lean6(c, P, counter, order, pcost)) {}
+    else if (c->occupancy >= 5) launch_persistent_occ<5>(c, P, counter, order, pcost);
     else launch_persistent_occ<4>(c, P, counter, order, pcost);
     // next launch's order from this launch's costs (stream-ordered, no host sync).  The view does not change between the frames of
     // a progressive render, so after the first few launches of a view the order is refreshed every feedback_every-th launch only

@@ -298,7 +298,7 @@ __device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk
 // (equal t goes to the lower slot = the leaf the reference's walk reaches first).  Used only while a
 // launch drains (persistent kernel): idle lanes shorten the few long rays that set the launch time.
 constexpr int WAVE_LDS_DWORDS = 24 * 64;  // per-wave LDS region of the persistent kernel (6 KiB): phase stash / cooperative stack
-constexpr int WIDE_STASH = 12;             // phase stash of the WIDE persistent kernel, dwords per lane (behind the WIDE_STACK stack words)
+constexpr int WIDE_STASH = 10;             // phase stash of the WIDE persistent kernel, dwords per lane (behind the WIDE_STACK stack words)
 constexpr int COOP_STACK = WAVE_LDS_DWORDS;   // node stack entries; a deeper frontier falls back to the plain walk
 
 __device__ __forceinline__ float wave_min_f32(float v) {

@@ -329,6 +329,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
               {"kernel": 1, "batch_frames": 1, "split_parts": 4, "split_steps": 32, "coop_rounds": 4, "split_waves": 50}, {"kernel": 1, "batch_frames": 3, "split_parts": 8, "split_steps": 16},
               {"kernel": 1, "batch_frames": 1, "split_parts": 8, "split_steps": 16, "split_waves": 400},
               {"kernel": 1, "batch_frames": 1, "split_parts": 1, "coop_rounds": 1},
+              {"kernel": 1, "occupancy": 6, "batch_frames": 32, "coop_tiles_per_wave": 0}, {"kernel": 1, "occupancy": 6, "batch_frames": 1},      # six waves per SIMD (lean wide build)
               {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 48},       # two paths per lane
               {"kernel": 1, "batch_frames": 4, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 32},
               {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 56},
@@ -344,7 +345,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         if base is None:
             base = acc
         assert np.array_equal(acc, base), opts
-    for k, v in {"kernel": 1, "occupancy": 5, "trav_min": 32, "park_min": 16, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 2, "coop_lanes": 8, "coop_rounds": 2,
+    for k, v in {"kernel": 1, "occupancy": 6, "trav_min": 32, "park_min": 16, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 2, "coop_lanes": 8, "coop_rounds": 2,
                  "split_parts": 4, "split_steps": 400, "split_waves": 12, "coop_tiles_per_wave": 32, "paired": 0, "roles": 0}.items():
         ctx.set_option(k, v)
     assert ctx.get_option("park_min") == 16 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
