@@ -6,7 +6,7 @@ set -e
 NAME=$1; FLAGS=$2
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/tools/_exp /tmp/exp_$NAME
-/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize $FLAGS --offload-arch=gfx950 -c $R/dogeray_amd/csrc/context.hip -o /tmp/exp_$NAME/context.o
+/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=0 $FLAGS --offload-arch=gfx950 -c $R/dogeray_amd/csrc/context.hip -o /tmp/exp_$NAME/context.o
 HOSTOBJ=$(ls $R/dogeray_amd/_build/*.cpp.o)
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o $R/tools/_exp/lib_$NAME.so $HOSTOBJ /tmp/exp_$NAME/context.o -pthread
 echo built tools/_exp/lib_$NAME.so

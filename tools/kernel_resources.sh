@@ -2,7 +2,7 @@
 # VGPRs / spills / LDS of every kernel in context.hip (compiles with -save-temps into /tmp/kres): tools/kernel_resources.sh [grep pattern] [extra flags]
 R=$(cd "$(dirname "$0")/.." && pwd)
 rm -rf /tmp/kres && mkdir -p /tmp/kres && cd /tmp/kres
-/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize $2 --offload-arch=gfx950 -c $R/dogeray_amd/csrc/context.hip -o ctx.o -save-temps 2>/dev/null
+/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=0 $2 --offload-arch=gfx950 -c $R/dogeray_amd/csrc/context.hip -o ctx.o -save-temps 2>/dev/null
 python3 - "$1" <<'PY'
 import re, sys
 t = open('/tmp/kres/context-hip-amdgcn-amd-amdhsa-gfx950.s').read()
