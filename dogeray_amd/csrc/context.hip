@@ -74,9 +74,10 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // next record is a leaf waits until PARK_MIN lanes have one (the leaf step -- exact box + triangle -- is the long
 // block, as the parked triangle test is in the threaded walk); its stack lives in the first WIDE_STACK words of
 // the wave's LDS region, the phase stash behind it.
-// COOP (wide walk): build with the work-sharing drain (idle lanes take over subtrees of the rays still walking).  It costs registers
-// (90 VGPRs instead of 84) and a block of code in the loop, so launches whose queue is long enough to hide their tail use the build
-// without it (launch_persistent picks).
+// COOP (wide walk): build with work sharing (lanes without a pixel take over subtrees of the rays still walking: once the queue is
+// empty, and from the start in the waves that hold a part of a split tile).  It costs registers (96 VGPRs: five waves per SIMD) and
+// code in the loop, so launches whose queue is long enough to hide their tail use the lean build (80 VGPRs and 26 KiB of LDS at
+// OCC = 6: six waves per SIMD; launch_persistent / launch_wide_lean6 pick).
 constexpr int MAX_REGIONS = 8;
 constexpr int WAVE_LOG_WAVES = 16384;    // waves the wave log (option wave_log) has room for
 constexpr size_t PIXEL_LOG_WORDS = DR_WAVE_LOG_DETAIL ? (size_t)2 * 4096 * 4096 : 0;   // experiment builds: start and end stamp of every pixel behind the wave log
@@ -87,11 +88,13 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
                                                                      unsigned* __restrict__ pixel_cost) {
   const int lane = threadIdx.x & 63;
   const int wave_id = blockIdx.x * 4 + (threadIdx.x >> 6);
-  // 6 KiB of LDS per wave, used for two things that never overlap in time within a wave:
-  //  * during the shade/refill phase, the state that phase does not need (the parked leaf, 1/direction,
-  //    and while a hit is shaded also the pixel bookkeeping) waits here -- the shading code is where
-  //    register pressure peaks, and this keeps the kernel at 96 VGPRs = 5 waves per SIMD;
-  //  * outside the phase, the node stack of the cooperative drain (COOP_STACK entries).
+  // LDS per wave (threaded walk: 6 KiB; wide walk: 6.5 KiB, 7.25 with work sharing), used for two things that never overlap in time
+  // within a wave:
+  //  * during the shade/refill phase, the state that phase does not need (threaded walk: the parked leaf, 1/direction; and while a
+  //    hit is shaded also the pixel bookkeeping) waits here -- the shading code is where register pressure peaks, and this keeps
+  //    the kernel within the VGPRs of its occupancy;
+  //  * outside the phase, the node stack of the threaded walk's cooperative drain (COOP_STACK entries) / the exchange words of
+  //    the wide walk's work sharing.  The wide walk's own stack (WIDE_STACK words per lane) sits in front of the stash.
   // WIDE && COOP: three more words per lane behind the stash -- the shared best hit (64-bit key) and the number of helper lanes of
   // a ray whose subtrees have been handed out (drain phase, below)
   constexpr int SHARE_OFF = (WIDE_STACK + WIDE_STASH) * 64;
