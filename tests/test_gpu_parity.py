@@ -268,6 +268,32 @@ def test_moving_camera_keeps_the_previous_views_tile_order(dr, orc, ctx, synth):
         _assert_frames(g, r, "moving camera, frame %d" % k)
 
 
+def test_wave_log_and_pixel_cost_of_a_single_frame(dr, ctx, synth):
+    """dr_stats_wave_log / dr_stats_pixel_cost (the measurement aids behind DESIGN 5's single-frame anatomy): every wave of a one-frame launch
+    logs begin <= queue empty <= end, every rendered pixel has a cost of at least one node step, and neither changes the frame."""
+    ps = dr.Scene.load(os.path.join(synth["dir"], "hf_small.rts"))
+    ps.build_bvh()
+    ctx.upload(ps)
+    s = ps.settings()
+    st = dr.pack_settings13(s, 1, spp=1)
+    W, H = 320, 192
+    plain = ctx.render_frame(st, W, H, s.background, 5)
+    ctx.set_option("wave_log", 1)
+    try:
+        again = ctx.render_frame(st, W, H, s.background, 5)
+        assert np.array_equal(plain, again)
+        log = ctx.wave_log()
+        assert len(log) > 0 and len(log) % 4 == 0
+        begin, empty, end = log[:, 0].astype(np.int64), log[:, 1].astype(np.int64), log[:, 2].astype(np.int64)
+        assert np.all(end >= begin) and np.all((empty == 0) | ((empty >= begin) & (empty <= end)))
+        assert np.all(empty > 0)                                  # every wave sees the queue run empty before it ends
+        cost = ctx.pixel_cost(W, H)
+        assert cost.shape == (W, H) and cost.min() >= 1 and cost.max() < 100000
+        assert ctx.pixel_times(W, H) is None                      # experiment builds only
+    finally:
+        ctx.set_option("wave_log", 0)
+
+
 def test_stripes_partition_the_frame(dr, ctx, synth):
     """Multi-GPU partition: block columns bx % R == r; the union over r is the 1-GPU frame."""
     ps = dr.Scene.load(os.path.join(synth["dir"], "hf_small.rts"))
