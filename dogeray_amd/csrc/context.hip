@@ -1416,7 +1416,7 @@ struct dr_context {
   bool order_valid = false;        // tile_order was computed for `order_key`
   int order_age = 0;               // launches since the view (order_key) changed
   int order_follows_camera = 1;    // a view with the same frame geometry but other settings starts from the previous view's tile order
-  int feedback_every = 8;          // ... the order is recomputed after the first four of them and then after every feedback_every-th
+  int feedback_every = 8;          // ... the order is recomputed after the first two of them and then after every feedback_every-th
   float order_key[18] = {0};       // settings13 + W, H, stripe, tile grid of the frame the order belongs to
   bool feedback = true;
   int stripe_mod = 1, stripe_rem = 0;
@@ -1706,10 +1706,10 @@ void enqueue_frame(dr_context* c, const RenderParams& P) {
     else if (c->occupancy >= 5) launch_persistent_occ<5>(c, P, counter, order, pcost);
     else launch_persistent_occ<4>(c, P, counter, order, pcost);
     // next launch's order from this launch's costs (stream-ordered, no host sync).  The view does not change between the frames of
-    // a progressive render, so after the first few launches of a view the order is refreshed every feedback_every-th launch only
+    // a progressive render, so after the first two launches of a view the order is refreshed every feedback_every-th launch only
     // (the two kernels take 75 us: nothing for a launch of 32 frames, 6 % of a launch of one)
     if (pcost && !order) c->order_age = 0;
-    if (pcost && (c->order_age < 4 || c->order_age % c->feedback_every == 0)) {
+    if (pcost && (c->order_age < 2 || c->order_age % c->feedback_every == 0)) {
       hipLaunchKernelGGL(tile_cost_kernel, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, c->stream, c->pixel_cost, c->tile_cost, tiles);
       hipLaunchKernelGGL(tile_order_kernel, dim3(1), dim3(1024), 0, c->stream, c->tile_cost, c->tile_order, c->region_start, tiles, P.regions, c->heavy_factor, c->split_steps,
                          c->split_parts > 1 ? (int)((long long)c->num_cus * (c->occupancy >= 5 ? 5 : 4) * 4 * c->split_waves / (100 * c->split_parts)) : 0);      // at most split_waves % of the waves start with a part of a split tile
