@@ -1162,78 +1162,83 @@ __device__ __forceinline__ unsigned block_exclusive_scan(unsigned v, unsigned& t
 }
 __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __restrict__ tile_cost, int* __restrict__ order,
                                                            int* __restrict__ region_start, int ntiles, int regions, int heavy_factor, int split_steps, int split_limit) {
+  constexpr int WAVES = 16, GROUPS = 8;                    // 1 024 threads; a wave reads GROUPS x 64 costs per round trip
   __shared__ unsigned hist[MAX_REGIONS * ORDER_BUCKETS];   // expensive tiles per (region, cost class)
   __shared__ unsigned base[MAX_REGIONS * ORDER_BUCKETS];
-  __shared__ unsigned light_in_region[MAX_REGIONS], light_before[MAX_REGIONS], heavy_in_region[MAX_REGIONS];
+  __shared__ unsigned light_cnt[WAVES][MAX_REGIONS];       // light tiles of a wave's range per region, then: of the waves before it
+  __shared__ unsigned light_in_region[MAX_REGIONS], light_before[MAX_REGIONS], light_start[MAX_REGIONS], split_tiles[MAX_REGIONS];
+  __shared__ int rb[MAX_REGIONS + 1];                      // first tile of region r (region_of(t) = t * regions / ntiles)
   __shared__ unsigned long long total_cost;
   const int nb = regions * ORDER_BUCKETS;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   for (int i = tid; i < nb; i += blockDim.x) hist[i] = 0;
-  if (tid < MAX_REGIONS) { light_in_region[tid] = 0; heavy_in_region[tid] = 0; }
+  if (tid < WAVES * MAX_REGIONS) (&light_cnt[0][0])[tid] = 0;
+  if (tid < MAX_REGIONS) split_tiles[tid] = 0;
+  if (tid <= regions) rb[tid] = (int)(((long long)tid * ntiles + regions - 1) / regions);
   if (tid == 0) total_cost = 0;
   __syncthreads();
-  // every thread owns one contiguous chunk of tiles (so that "natural order" is a plain prefix sum); it reads the costs eight at a
-  // time (independent loads: one round trip per eight tiles, three passes) and keeps the region of its current tile as it goes
-  const int chunk = (ntiles + (int)blockDim.x - 1) / (int)blockDim.x;
-  const int t0 = tid * chunk < ntiles ? tid * chunk : ntiles, t1 = (t0 + chunk < ntiles) ? t0 + chunk : ntiles;
-  auto region_of = [&](int t) { return (int)(((long long)t * regions) / ntiles); };
-  auto region_end = [&](int r) { return (int)(((long long)(r + 1) * ntiles + regions - 1) / regions); };      // first tile of region r + 1
-  auto for_chunk = [&](auto&& body) {
-    int r = t0 < t1 ? region_of(t0) : 0, rend = region_end(r);
-    for (int tb = t0; tb < t1; tb += 8) {
-      unsigned v[8];
+  // Wave w owns the contiguous range [w0, w1) of the tile numbering and walks it 64 tiles at a time, lane l on tile g + l: the light
+  // tiles keep their natural order through ballots and prefix counts (a range at a time, a region at a time), the expensive ones are
+  // binned by cost class.  (One thread per 32-tile chunk with everything per tile took 70-100 us on the one CU this block has.)
+  const int per = ((ntiles + WAVES - 1) / WAVES + 63) & ~63;
+  const int w0 = w * per < ntiles ? w * per : ntiles, w1 = w0 + per < ntiles ? w0 + per : ntiles;
+  auto mbcnt = [](unsigned long long m) { return (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u)); };
+  // body(t, cost, valid, rcur): rcur = region of the 64-tile group's first tile (wave-uniform); a lane's own region is rcur or rcur + 1
+  auto for_range = [&](auto&& body) {
+    int rcur = 0;
+    while (rcur + 1 < regions && w0 >= rb[rcur + 1]) rcur++;
+    for (int g0 = w0; g0 < w1; g0 += 64 * GROUPS) {
+      unsigned v[GROUPS];
 #pragma unroll
-      for (int k = 0; k < 8; k++) v[k] = tb + k < t1 ? tile_cost[tb + k] : 0u;
+      for (int k = 0; k < GROUPS; k++) { const int t = g0 + 64 * k + lane; v[k] = t < w1 ? tile_cost[t] : 0u; }
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        if (tb + k < t1) {
-          while (tb + k >= rend) { r++; rend = region_end(r); }
-          body(tb + k, v[k], r);
+      for (int k = 0; k < GROUPS; k++) {
+        const int g = g0 + 64 * k;
+        if (g < w1) {
+          while (rcur + 1 < regions && g >= rb[rcur + 1]) rcur++;
+          body(g + lane, v[k], g + lane < w1, rcur);
         }
       }
     }
   };
   {
     unsigned long long sum = 0;
-    for_chunk([&](int, unsigned cost, int) { sum += cost; });
-    atomicAdd(&total_cost, sum);
+    for_range([&](int, unsigned cost, bool, int) { sum += cost; });
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) atomicAdd(&total_cost, sum);
   }
   __syncthreads();
   const unsigned long long threshold = heavy_factor > 0 ? (total_cost * (unsigned long long)heavy_factor) / (unsigned long long)(ntiles > 0 ? ntiles : 1)
                                                        : (heavy_factor < 0 ? 0ull : ~0ull);       // -1: every tile by cost, 0: all natural
-  auto heavy = [&](unsigned cost) { return (unsigned long long)cost > threshold; };
   auto key_of = [&](unsigned cost, int r) {
     unsigned b = cost >> 4; if (b > ORDER_BUCKETS - 1) b = ORDER_BUCKETS - 1;
     return r * ORDER_BUCKETS + (ORDER_BUCKETS - 1 - (int)b);      // ascending key = region, then most expensive first
   };
-  // tiles whose longest pixel took at least split_steps node steps (a whole cost class: they are a prefix of their region's order):
-  // launches of one frame hand them out in parts (render_persistent_kernel, nsplit)
-  __shared__ unsigned split_tiles[MAX_REGIONS];
-  if (tid < MAX_REGIONS) split_tiles[tid] = 0;
+  // count: expensive tiles per class; tiles whose longest pixel took at least split_steps node steps (a whole cost class: they are a
+  // prefix of their region's order; launches of one frame hand them out in parts, render_persistent_kernel nsplit); light tiles per
+  // (wave, region)
+  for_range([&](int t, unsigned cost, bool valid, int rcur) {
+    const int r = rcur + ((rcur + 1 < regions && t >= rb[rcur + 1]) ? 1 : 0);
+    const bool heavy = valid && (unsigned long long)cost > threshold;
+    if (heavy) {
+      atomicAdd(&hist[key_of(cost, r)], 1u);
+      if (split_steps > 0 && (cost >> 4) >= (unsigned)(split_steps >> 4)) atomicAdd(&split_tiles[r], 1u);
+    }
+    const bool light = valid && !heavy;
+    const unsigned long long b0 = __ballot(light && r == rcur), b1 = __ballot(light && r != rcur);
+    if (lane == 0) { light_cnt[w][rcur] += (unsigned)__popcll(b0); if (b1) light_cnt[w][rcur + 1] += (unsigned)__popcll(b1); }
+  });
   __syncthreads();
-  unsigned my_light = 0;
-  {
-    // (the light tiles of a region are counted per thread and added once: tens of thousands of atomics on ONE LDS word took 40 us)
-    int cur = -1; unsigned run = 0;
-    for_chunk([&](int, unsigned cost, int r) {
-      if (heavy(cost) && split_steps > 0 && (cost >> 4) >= (unsigned)(split_steps >> 4)) atomicAdd(&split_tiles[r], 1u);
-      if (heavy(cost)) atomicAdd(&hist[key_of(cost, r)], 1u);
-      else {
-        my_light++;
-        if (r != cur) { if (run) atomicAdd(&light_in_region[cur], run); cur = r; run = 0; }
-        run++;
-      }
-    });
-    if (run) atomicAdd(&light_in_region[cur], run);
+  // positions: region r's expensive tiles by class, then its light tiles
+  if (tid < regions) {
+    unsigned run = 0;
+    for (int k = 0; k < WAVES; k++) { const unsigned n = light_cnt[k][tid]; light_cnt[k][tid] = run; run += n; }      // now: light tiles of region tid in the waves before k
+    light_in_region[tid] = run;
   }
-  __syncthreads();
-  // positions: region r's expensive tiles by class, then its light tiles; all prefix sums by the whole block (a single thread
-  // walking the 1 024 + 2 048 counters took 0.1 ms -- per frame when every launch is one frame)
-  unsigned total_light, total_heavy;
-  const unsigned light_rank0 = block_exclusive_scan(my_light, total_light);         // global rank of this thread's first light tile
+  unsigned total_heavy;
   const int i0 = tid * 2;                                                            // nb <= 2 * blockDim.x
   const unsigned h0 = i0 < nb ? hist[i0] : 0u, h1 = i0 + 1 < nb ? hist[i0 + 1] : 0u;
-  const unsigned heavy_before = block_exclusive_scan(h0 + h1, total_heavy);         // expensive tiles in the classes before i0
+  const unsigned heavy_before = block_exclusive_scan(h0 + h1, total_heavy);         // expensive tiles in the classes before i0 (syncs the block)
   if (tid == 0) {
     unsigned lights = 0;
     for (int r = 0; r < regions; r++) { light_before[r] = lights; lights += light_in_region[r]; }      // light tiles in the regions before r
@@ -1245,20 +1250,26 @@ __global__ __launch_bounds__(1024) void tile_order_kernel(const unsigned* __rest
   if (tid < regions) {
     region_start[tid] = (int)base[tid * ORDER_BUCKETS];
     const unsigned heavy_through = tid + 1 < regions ? base[(tid + 1) * ORDER_BUCKETS] - light_before[tid + 1] : total_heavy;
-    heavy_in_region[tid] = heavy_through + light_before[tid];                        // where region r's light tiles begin
+    light_start[tid] = heavy_through + light_before[tid];                            // where region r's light tiles begin
     const int limit = split_limit / regions;                                         // (any prefix of a region's order will do)
     region_start[MAX_REGIONS + 1 + tid] = (int)split_tiles[tid] < limit ? (int)split_tiles[tid] : limit;
   }
-  if (tid == 0) region_start[regions] = (int)(total_heavy + total_light);
+  if (tid == 0) region_start[regions] = ntiles;
   __syncthreads();
-  unsigned light_rank = light_rank0;
-  for_chunk([&](int t, unsigned cost, int r) {
-    if (heavy(cost)) {
-      order[atomicAdd(&base[key_of(cost, r)], 1u)] = t;
-    } else {
-      order[heavy_in_region[r] + (light_rank - light_before[r])] = t;
-      light_rank++;
+  // place
+  int placed_r = -1; unsigned placed0 = 0, placed1 = 0;      // light tiles of this wave already placed in regions placed_r and placed_r + 1
+  for_range([&](int t, unsigned cost, bool valid, int rcur) {
+    if (rcur != placed_r) { placed0 = rcur == placed_r + 1 ? placed1 : 0u; placed1 = 0u; placed_r = rcur; }
+    const int r = rcur + ((rcur + 1 < regions && t >= rb[rcur + 1]) ? 1 : 0);
+    const bool heavy = valid && (unsigned long long)cost > threshold;
+    if (heavy) order[atomicAdd(&base[key_of(cost, r)], 1u)] = t;
+    const bool light = valid && !heavy;
+    const unsigned long long b0 = __ballot(light && r == rcur), b1 = __ballot(light && r != rcur);
+    if (light) {
+      if (r == rcur) order[light_start[r] + light_cnt[w][r] + placed0 + mbcnt(b0)] = t;
+      else order[light_start[r] + light_cnt[w][r] + placed1 + mbcnt(b1)] = t;
     }
+    placed0 += (unsigned)__popcll(b0); placed1 += (unsigned)__popcll(b1);
   });
 }
 
