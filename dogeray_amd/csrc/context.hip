@@ -1646,7 +1646,8 @@ bool launch_wide_lean6(dr_context* c, const RenderParams& P_in, unsigned* counte
   if (P.coop_steps > 0 && work < (long long)c->coop_tiles_per_wave * c->num_cus * 5 * 4) return false;      // a short launch: work-sharing build
   int blocks = c->num_cus * 6;
   if ((long long)blocks * 4 > work) blocks = (int)((work + 3) / 4);
-  P.wave_log = nullptr; c->wave_log_waves = 0;
+  if (!DR_WAVE_LOG_DETAIL || blocks * 4 > WAVE_LOG_WAVES) P.wave_log = nullptr;      // only experiment builds log the lean kernel's waves
+  c->wave_log_waves = P.wave_log ? blocks * 4 : 0;
   hipLaunchKernelGGL((render_persistent_kernel<false, 6, 32, 16, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, c->stream, P, counter, order,
                      order ? c->region_start : nullptr, pixel_cost);
   return true;
