@@ -154,19 +154,30 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *   "kernel"        DR_KERNEL_PERSISTENT (default): waves are pools of 64 path slots that refill
  *                   from a tile queue; DR_KERNEL_TILE: one wave per 8x8 tile, the reference's launch shape
  *   "batch_frames"  most frames one launch of dr_render_accumulate covers (persistent kernel), default 32
- *   "feedback"      1 (default): tiles are started most-expensive-first using the previous launch's costs
- *   "occupancy"     waves per SIMD: 5 (default) or 4 for the persistent kernel, 4 or 6 for the tile kernel
+ *   "feedback"      1 (default): tiles are started most-expensive-first using the previous launch's costs; the order of a view
+ *                   is recomputed after its first two launches and then after every "feedback_every"-th (8); a view that differs
+ *                   from the last one only in its settings (a moving camera) starts from the last view's order
+ *                   ("order_follows_camera", default 1)
+ *   "occupancy"     waves per SIMD.  Persistent kernel: 6 (default: six for the wide walk's lean build of long launches, five for
+ *                   every other build), 5 or 4; tile kernel: 4 or 6
  *   "trav_min"      32 or 48;  "park_min"  0, 8 or 16 (default);  "unroll"  1, 2 (default) or 3   (persistent kernel scheduling)
  *   "xcd_regions"   1 (default): one tile queue per XCD, each an image band, with stealing; 0: one queue
  *   "heavy_factor"  with feedback: tiles that cost more than this many times the mean start first (most expensive
  *                   first), all others keep their natural order (default 1: the above-average tiles; 0: no tile is
  *                   reordered, -1: every tile by cost)
- *   "coop_steps"    drain phase (the tile queue is empty).  Wide walk: a ray older than this many steps (default 8, 0 = off) hands
- *                   the oldest word of its stack -- a subtree -- to a lane that has no pixel left; all lanes of one ray keep
- *                   the best hit in one LDS word and the owner shades when every piece is done.  The kernel build that contains
- *                   this is used for launches with fewer than "coop_tiles_per_wave" (32) tiles per wave: short launches,
- *                   whose tail shows.  Threaded walk: such a ray is finished by all 64 lanes breadth-first, in waves with at
- *                   most "coop_lanes" (8) lanes walking
+ *   "coop_steps"    work sharing (the tile queue is empty, or the wave holds a part of a split tile).  Wide walk: a ray older than
+ *                   this many steps (default 2, 0 = off) hands the oldest word of its stack -- a subtree -- to a lane that has no
+ *                   pixel, up to "coop_rounds" (2) times per loop iteration; all lanes of one ray keep the best hit in one LDS
+ *                   word and the owner shades when every piece is done.  The kernel build that contains this is used for
+ *                   launches with fewer than "coop_tiles_per_wave" (32) tiles per wave: short launches, whose tail shows; they
+ *                   use one tile queue ("short_one_queue", default 1).
+ *   "split_parts"   launches of ONE frame: the tiles whose longest pixel took "split_steps" (400) node steps in the previous
+ *                   frame -- as many of them as give "split_waves" (12) per cent of the waves a part to start with -- are handed
+ *                   out in this many parts (4; 1 = whole, 2, 8); the wave holds until those pixels are done and its other lanes
+ *                   help with their rays from the first step
+ *                   Threaded walk ("coop_steps" again): once the queue is empty, a ray older than that is finished by all 64
+ *                   lanes breadth-first, in waves with at most "coop_lanes" (8) lanes walking
+ *   "wave_log"      1: short launches record begin / queue empty / end of every wave (dr_stats_wave_log)
  *   "paired"        wide walk, launches with many tiles per wave: 1 = every lane owns two paths (one walked, one waiting to be
  *                   shaded or holding the next ray), phase once "pair_thresh" (32, 48, 56) lanes have one to service; measured
  *                   slower than the default one-path kernel, so 0 by default
