@@ -23,7 +23,8 @@ pool = {"coop_steps": [1, 2, 8], "coop_rounds": [1, 2, 5], "split_parts": [1, 2,
         "batch_frames": [1, 2, 3, 32], "feedback_every": [1, 8], "coop_tiles_per_wave": [0, 32, 100000], "park_min": [0, 8, 16], "unroll": [1, 2]}
 bad = frames = 0
 for k in range(n_scenes):
-    W = int(rng.choice([64, 96, 100, 131, 200, 320])); H = int(rng.choice([40, 64, 75, 128, 192]))
+    sizes = [int(v) for v in os.environ["FUZZ_SIZES"].split(",")] if os.environ.get("FUZZ_SIZES") else None      # e.g. FUZZ_SIZES=8,9,16,24,33: tiny frames
+    W = int(rng.choice(sizes or [64, 96, 100, 131, 200, 320])); H = int(rng.choice(sizes or [40, 64, 75, 128, 192]))
     nobj = int(rng.integers(2, 1500))
     path = random_scene(rng, nobj, os.path.join(d, "f%d.rts" % k), W=W, H=H, textures=names)
     ps = dr.Scene.load(path, tex); ps.build_bvh()
