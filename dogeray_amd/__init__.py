@@ -107,10 +107,12 @@ _API = [
     ("dr_context_stream", C.c_int, [_VP, C.POINTER(_VP)]),
     ("dr_accum_pack_stripe", C.c_int, [_VP, C.c_int, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
     ("dr_accum_unpack_stripes", C.c_int, [_VP, _VP, C.c_uint64, C.c_int, C.c_int, _VP]),
+    ("dr_accum_reserve_pack", C.c_int, [_VP, C.c_int]),
     ("dr_group_create", C.c_int, [C.c_int, _VP, C.POINTER(_VP)]),
     ("dr_group_destroy", None, [_VP]),
     ("dr_group_size", C.c_int, [_VP]),
     ("dr_group_uses_rccl", C.c_int, [_VP]),
+    ("dr_group_rccl_ranks", C.c_int, [_VP]),
     ("dr_group_context", _VP, [_VP, C.c_int]),
     ("dr_group_upload_scene", C.c_int, [_VP, _VP]),
     ("dr_group_accum_reset", C.c_int, [_VP, C.c_int, C.c_int]),
@@ -118,6 +120,7 @@ _API = [
     ("dr_stats_enable_counters", C.c_int, [_VP, C.c_int]),
     ("dr_stats_reset", C.c_int, [_VP]),
     ("dr_stats_get", C.c_int, [_VP, C.POINTER(DrStats)]),
+    ("dr_stats_kernel_diag", C.c_int, [_VP, C.POINTER(C.c_ulonglong), C.c_int]),
     ("dr_stats_wave_log", C.c_int, [_VP, C.POINTER(C.c_ulonglong), C.c_int, C.POINTER(C.c_int)]),
     ("dr_stats_pixel_cost", C.c_int, [_VP, C.POINTER(C.c_uint), C.c_size_t, C.POINTER(C.c_size_t)]),
     ("dr_stats_pixel_times", C.c_int, [_VP, C.POINTER(C.c_uint), C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -385,6 +388,12 @@ class Context:
         _check(lib().dr_stats_get(self._h, C.byref(s)))
         return s.as_dict()
 
+    def kernel_diag(self, n=16):
+        """Diagnostic words of the pool kernel's counting build (option pool_diag), see dr_stats_kernel_diag."""
+        buf = (C.c_ulonglong * n)()
+        _check(lib().dr_stats_kernel_diag(self._h, buf, n))
+        return [int(v) for v in buf]
+
     def wave_log(self, max_waves=16384):
         """(n, 16) uint64: begin, queue-empty, end stamps (100 MHz ticks) and iterations after the queue was empty, per wave of the
         last persistent launch; needs set_option("wave_log", 1) before the launch."""
@@ -502,6 +511,11 @@ class Group:
     @property
     def uses_rccl(self):
         return bool(lib().dr_group_uses_rccl(self._h))
+
+    @property
+    def rccl_ranks(self):
+        """Ranks of the RCCL communicator (ncclCommCount); 0 with the copy transport."""
+        return int(lib().dr_group_rccl_ranks(self._h))
 
     def context(self, rank):
         """Borrowed Context of one rank (owned by the group: do not close it)."""

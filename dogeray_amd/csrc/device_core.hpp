@@ -588,7 +588,6 @@ __device__ __forceinline__ Hit closest_hit_threaded(WalkRsrc walk, V3 o, V3 d, C
 // boxes; the far child waits on a per-lane stack in LDS (one dword per level, lane-major, so
 // a wave's pushes and pops never bank-conflict).  The tree is a median split, so its depth is
 // ceil(log2 N) <= 24 for N <= 2^24 (the host refuses deeper trees for this mode).
-constexpr int ORDERED_STACK = 24;
 
 template <bool COUNT>
 __device__ __forceinline__ Hit closest_hit_ordered(const DevPair* __restrict__ pairs, const DevPrim* __restrict__ prims,

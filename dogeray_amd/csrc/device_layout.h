@@ -44,6 +44,7 @@ constexpr int WIDE_UNITS = 4;
 constexpr int WIDE_INDEX_BITS = 24;                   // records < 2^24 (1 GiB of them)
 constexpr int WIDE_STACK = 16;                        // stack words per lane kept in LDS (one more lives in a register)
 constexpr int WIDE_MAX_DEPTH = WIDE_STACK + 1;        // most nodes on a root-to-leaf path the kernel can walk
+constexpr int ORDERED_STACK = 24;                     // ordered traversal: levels of its per-lane stack (median split: depth <= ceil(log2 N))
 
 // Ordered traversal: record k describes the two children of internal node k (pre-order index
 // of the internal node among ALL nodes is kept in `DevNode`; pairs are indexed by node id).

@@ -38,6 +38,8 @@ struct Rccl {
   void* handle = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
   ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -53,12 +55,14 @@ struct Rccl {
     auto sym = [&](const char* n) { return dlsym(handle, n); };
     CommInitAll = (decltype(CommInitAll))sym("ncclCommInitAll");
     CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+    CommAbort = (decltype(CommAbort))sym("ncclCommAbort");
+    CommCount = (decltype(CommCount))sym("ncclCommCount");
     GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
     GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
     Send = (decltype(Send))sym("ncclSend");
     Recv = (decltype(Recv))sym("ncclRecv");
     GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
-    return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv && GetErrorString;
+    return CommInitAll && CommDestroy && CommAbort && CommCount && GroupStart && GroupEnd && Send && Recv && GetErrorString;
   }
 };
 
@@ -91,7 +95,21 @@ struct dr_group {
   Rendezvous meet;
   std::string error;                               // first failure of a worker
   std::mutex error_lock;
-  void fail(const std::string& msg) { { std::lock_guard<std::mutex> g(error_lock); if (error.empty()) error = msg; } meet.abort(); }
+  bool broken = false;                             // a rank failed under RCCL: the communicators were aborted, the group can only be destroyed
+  // A rank that fails leaves its peers with transfers that will never be matched: rank 0 has already queued grouped ncclRecv
+  // calls for it, and hipStreamSynchronize(comm) / the join would wait for ever.  So the first failure aborts every
+  // communicator (ncclCommAbort cancels outstanding send / recv; the waiting threads then return) and releases the copy
+  // transport's rendezvous.  The group is unusable afterwards and says so.
+  void fail(const std::string& msg) {
+    bool first = false;
+    { std::lock_guard<std::mutex> g(error_lock); if (error.empty()) { error = msg; first = true; } }
+    if (first && use_rccl) {
+      std::lock_guard<std::mutex> g(error_lock);
+      broken = true;
+      for (ncclComm_t& c : comms) if (c) { (void)rccl.CommAbort(c); c = nullptr; }
+    }
+    meet.abort();
+  }
 };
 
 namespace {
@@ -138,6 +156,9 @@ bool rank_work(dr_group* g, int r, const float* st, int W, int H, float bg, uint
     G_HIP(hipStreamWaitEvent(comm, g->packed[slot][(size_t)r], 0));
     int32_t* stage = g->stage[slot];
     if (copy) {
+      // stage[slot] was last read by rank 0's unpack of batch - 2, whose end is sent[slot][0] (recorded before that batch's second
+      // rendezvous, so it exists by now): the copy into the same staging stripe may not overtake it
+      if (r != 0 && batch >= 2) G_HIP(hipStreamWaitEvent(comm, g->sent[slot][0], 0));
       if (r != 0 && bytes) G_HIP(hipMemcpyPeerAsync(stage + (size_t)r * g->stage_stride, g->device[0], pk, g->device[(size_t)r], bytes, comm));
       G_HIP(hipEventRecord(g->sent[slot][(size_t)r], comm));
       g->meet.arrive();                                        // every rank has recorded sent(batch)
@@ -268,9 +289,16 @@ void dr_group_destroy(dr_group* g) {
 int dr_group_size(const dr_group* g) { return g ? g->n : DR_ERR_INVALID; }
 dr_context* dr_group_context(dr_group* g, int rank) { return (g && rank >= 0 && rank < g->n) ? g->ctx[(size_t)rank] : nullptr; }
 int dr_group_uses_rccl(const dr_group* g) { return g && g->use_rccl ? 1 : 0; }
+int dr_group_rccl_ranks(const dr_group* g) {
+  if (!g || !g->use_rccl || g->comms.empty() || !g->comms[0]) return 0;
+  int n = 0;
+  if (g->rccl.CommCount(g->comms[0], &n) != ncclSuccess) return 0;
+  return n;
+}
 
 int dr_group_upload_scene(dr_group* g, const dr_scene* s) {
   if (!g || !s) { set_error("null argument"); return DR_ERR_INVALID; }
+  if (g->broken) { set_error("group: unusable after a failed call (its RCCL communicators were aborted); destroy it"); return DR_ERR_DEVICE; }
   g->error.clear();
   const bool ok = for_all_ranks(g, [&](int r) {
     if (dr_context_upload_scene(g->ctx[(size_t)r], s) != DR_OK) { g->fail(std::string("upload on rank ") + std::to_string(r) + ": " + dr_last_error()); return false; }
@@ -282,8 +310,11 @@ int dr_group_upload_scene(dr_group* g, const dr_scene* s) {
 
 int dr_group_accum_reset(dr_group* g, int W, int H) {
   if (!g || W <= 0 || H <= 0) { set_error("bad argument"); return DR_ERR_INVALID; }
-  for (int r = 0; r < g->n; r++)
+  for (int r = 0; r < g->n; r++) {
     if (dr_accum_reset(g->ctx[(size_t)r], W, H) != DR_OK) return DR_ERR_DEVICE;
+    // both pack buffers now, not inside the first gathers of a timed region (dr_accum_pack_stripe allocates on first use)
+    if (g->n > 1 && r != 0 && (dr_accum_reserve_pack(g->ctx[(size_t)r], 0) != DR_OK || dr_accum_reserve_pack(g->ctx[(size_t)r], 1) != DR_OK)) return DR_ERR_NOMEM;
+  }
   const size_t stride = (stripe_elems(W, H, g->n, 0) + 3) & ~(size_t)3;          // rank 0 owns the most columns; 16-byte multiple
   if (g->n > 1 && (stride != g->stage_stride || !g->stage[0])) {
     if (hipSetDevice(g->device[0]) != hipSuccess) { set_error("group: hipSetDevice"); return DR_ERR_DEVICE; }
@@ -301,6 +332,7 @@ int dr_group_render_accumulate(dr_group* g, const float settings13[13], int W, i
                                uint64_t seed_stride, int nframes, int gather_every) {
   if (!g || !settings13 || nframes < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
   if (g->W != W || g->H != H) { set_error("call dr_group_accum_reset(W, H) first"); return DR_ERR_INVALID; }
+  if (g->broken) { set_error("group: unusable after a failed call (its RCCL communicators were aborted); destroy it"); return DR_ERR_DEVICE; }
   if (nframes == 0) return DR_OK;
   const int every = gather_every > 0 ? gather_every : nframes;
   g->error.clear();

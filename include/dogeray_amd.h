@@ -231,6 +231,9 @@ int dr_accum_device_ptr(dr_context* c, void** dev_ptr, uint64_t* bytes);
  * r, r+world, ..., on hip_stream (NULL: the context's stream).  Ranks render disjoint columns, so the unpack may run
  * beside the gathering rank's own rendering. */
 int dr_accum_pack_stripe(dr_context* c, int slot, void** dev_ptr, uint64_t* bytes);
+/* allocates pack buffer `slot` for the current accumulator and stripe without packing (so that no allocation falls into a
+ * timed or latency-critical gather; dr_group_accum_reset does this for every rank) */
+int dr_accum_reserve_pack(dr_context* c, int slot);
 int dr_accum_unpack_stripes(dr_context* c, const void* packed_dev, uint64_t rank_stride_bytes, int world, int first_rank,
                             void* hip_stream);
 
@@ -246,6 +249,7 @@ int dr_group_create(int n, const int* device_ordinals, dr_group** out);
 void dr_group_destroy(dr_group* g);
 int dr_group_size(const dr_group* g);
 int dr_group_uses_rccl(const dr_group* g);
+int dr_group_rccl_ranks(const dr_group* g);   /* ranks of the RCCL communicator (ncclCommCount), 0 when the copy transport is used */
 dr_context* dr_group_context(dr_group* g, int rank);
 int dr_group_upload_scene(dr_group* g, const dr_scene* s);
 int dr_group_accum_reset(dr_group* g, int W, int H);
@@ -271,6 +275,12 @@ typedef struct dr_stats {
 int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the kernel; off by default */
 int dr_stats_reset(dr_context* c);
 int dr_stats_get(dr_context* c, dr_stats* out);
+
+/* Diagnostics of the pool kernel's counting build (option "pool_diag" = 1), summed over waves since dr_stats_reset, n <= 48 words:
+ * [0..2] batches of the node / leaf / shade stage, [3..5] paths in those batches, [6] shader cycles spent choosing and claiming
+ * batches (waiting included), [7..9] cycles inside the node / leaf / shade step, [10] cycles pushing, [11] polls that waited for a
+ * fuller batch, [12] lost claims, [13] polls that found nothing. */
+int dr_stats_kernel_diag(dr_context* c, unsigned long long* out, int n);
 
 /* Timeline of the last SHORT persistent-kernel launch (fewer than coop_tiles_per_wave tiles per wave: one frame, a thin stripe;
  * option "wave_log" = 1 before the launch): sixteen words per wave --

@@ -159,7 +159,10 @@ def _render_pair(dr, orc, ctx, path, texdir, W, H, div, seed, spp=None, depth=No
     stats = ctx.stats()
     ctx.enable_counters(False)
     g2 = ctx.render_frame(st, W, H, s.background, seed)     # the timed (non-counting) build of the kernel
-    assert np.array_equal(g, g2), "counting and non-counting kernels disagree"
+    if not np.array_equal(g, g2):
+        bad = np.argwhere(np.any(g != g2, axis=2))
+        raise AssertionError("counting and non-counting kernels disagree at %d pixels of %s, first (x, y): %r; counting %r, non-counting %r"
+                             % (len(bad), os.path.basename(path), bad[:8].tolist(), g[tuple(bad[0])].tolist(), g2[tuple(bad[0])].tolist()))
     r, rc = os_.render(st, W, H, s.background, seed, nthreads=4)
     ctx.set_traversal(dr.TRAVERSAL_WIDE)       # the defaults
     ctx.set_option("kernel", 1)
@@ -575,6 +578,8 @@ def test_two_paths_per_lane_kernel_renders_like_the_oracle(dr, orc, ctx, synth, 
                         "*,0,-2.5,7,0.6,0,-0.5,0,7,50,6,4,0.9,synth_env.ppm,192,128")
     cases = [(mb4, synth["tex"], 192, 128), (os.path.join(SCENES, "scene.rts"), "", 320, 192), (os.path.join(SCENES, "glass.rts"), "", 200, 120),
              (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192), (os.path.join(synth["dir"], "city_small.rts"), "", 100, 70)]
+    if not ctx.get_option("experimental"):
+        pytest.skip("render_paired_kernel is only in -DDOGERAY_EXPERIMENTAL builds of the library (tools/exp_variant.sh)")
     ctx.set_option("paired", 1)
     ctx.set_option("coop_tiles_per_wave", 0)
     try:
@@ -625,6 +630,8 @@ def test_waves_with_roles_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tm
                         "*,0,-2.5,7,0.6,0,-0.5,0,7,50,6,4,0.9,synth_env.ppm,192,128")
     cases = [(mb4, synth["tex"], 192, 128), (os.path.join(SCENES, "scene.rts"), "", 320, 192), (os.path.join(SCENES, "glass.rts"), "", 200, 120),
              (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192), (os.path.join(synth["dir"], "city_small.rts"), "", 100, 70)]
+    if not ctx.get_option("experimental"):
+        pytest.skip("render_roles_kernel is only in -DDOGERAY_EXPERIMENTAL builds of the library (tools/exp_variant.sh)")
     ctx.set_option("coop_tiles_per_wave", 0)
     try:
         for roles in (3, 7, 6):
@@ -635,3 +642,57 @@ def test_waves_with_roles_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tm
     finally:
         ctx.set_option("roles", 0)
         ctx.set_option("coop_tiles_per_wave", 32)
+
+
+def test_pool_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
+    """render_pool_kernel (kernels_pool.hip; the default for long launches, forced here with option "pool" = 2): paths live in a
+    workgroup-wide pool in LDS and node / leaf / shade steps run as batches taken from queues.  Every material, textures, spheres,
+    margins of the preview divisor, frames that are not multiples of 8, fuzzed scenes with coincident triangles, batch fill
+    thresholds from 1 to 64 -- frames identical to the oracle's."""
+    from scene_fuzz import random_scene
+    rng = np.random.default_rng(2024)
+    names = ["synth_albedo.ppm", "synth_rough.ppm", "synth_env.ppm", "a.ppm"]
+    cube = with_settings(os.path.join(SCENES, "cube.rts"), str(tmp_path / "cube256.rts"), CUBE_SETTINGS)
+    cases = [(cube, "", 256, 256, 1), (cube, "", 256, 256, 4), (os.path.join(SCENES, "scene.rts"), "", 320, 192, 1), (os.path.join(SCENES, "glass.rts"), "", 200, 120, 1),
+             (os.path.join(synth["dir"], "matball.rts"), synth["tex"], 256, 256, 1), (os.path.join(SCENES, "cow.rts"), synth["tex"], 320, 192, 1),
+             (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192, 1), (os.path.join(synth["dir"], "hf_small.rts"), "", 320, 192, 1),
+             (os.path.join(synth["dir"], "bunny_small.rts"), "", 203, 117, 1), (os.path.join(synth["dir"], "city_small.rts"), "", 640, 360, 1)]
+    cases += [(random_scene(rng, int(rng.integers(2, 900)), str(tmp_path / ("pool%d.rts" % k)), W=96, H=64, textures=names), synth["tex"], 96, 64, 1) for k in range(8)]
+    ctx.set_option("pool", 2)
+    try:
+        for fill in (48, 1, 64):
+            ctx.set_option("pool_min_fill", fill)
+            for path, tex, W, H, div in cases:
+                g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, div, 777, spp=1, mode=2, kernel=1)      # (more samples per pixel go to the persistent kernel)
+                _assert_frames(g, r, "%s pool kernel, min fill %d" % (os.path.basename(path), fill))
+    finally:
+        ctx.set_option("pool", 1)
+        ctx.set_option("pool_min_fill", 48)
+
+
+def test_pool_kernel_batched_accumulation(dr, orc, ctx, synth):
+    """Several frames per launch of the pool kernel (one tile queue over all of them, atomic adds): the accumulator equals the sum
+    of the oracle's frames; with the tile order of the cost feedback, with and without one queue per XCD."""
+    path = os.path.join(synth["dir"], "city_small.rts")
+    ps, os_ = _load_both(dr, orc, path)
+    ctx.upload(ps)
+    s = ps.settings()
+    st = dr.pack_settings13(s, 1)
+    W, H, n = 640, 360, 7
+    total = np.zeros((W, H, 3), dtype=np.int64)
+    for k in range(n):
+        f, _ = os_.render(st, W, H, s.background, 5 + 1000003 * k, nthreads=4)
+        total += f
+    ctx.set_option("pool", 2)
+    try:
+        for regions in (1, 0):
+            ctx.set_option("xcd_regions", regions)
+            ctx.set_option("short_one_queue", 0)
+            for rep in range(3):          # the second and third launch run with the order the first one's costs gave
+                ctx.accum_reset(W, H)
+                ctx.render_accumulate(st, W, H, s.background, 5, 1000003, n)
+                assert np.array_equal(ctx.accum_read().astype(np.int64), total), (regions, rep)
+    finally:
+        ctx.set_option("pool", 1)
+        ctx.set_option("xcd_regions", 1)
+        ctx.set_option("short_one_queue", 1)
