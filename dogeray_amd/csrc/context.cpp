@@ -41,11 +41,11 @@ struct dr_context {
   // multi-GPU gather: two packed copies of this context's stripe (double buffer), sized for the accumulator
   int32_t* packed[2] = {nullptr, nullptr}; size_t packed_elems[2] = {0, 0};
   void* paths = nullptr; size_t paths_waves = 0;        // experimental kernels: path records in global memory (16-byte units)
-  unsigned* abort_flag = nullptr;                        // pool kernel (and the experimental roles kernel): set by a wave that waited too long (protocol failure)
+  unsigned* abort_flag = nullptr;                        // experimental roles kernel: set by a wave that waited too long (protocol failure)
   bool abort_used = false;                               // a launch that may set it has been queued since the last check
   int pool = 1;             // wide walk: 1 = long launches run the pool kernel (kernels_pool.hip), 2 = every launch it can render, 0 = never (persistent kernel)
   int pool_diag = 0;        // pool kernel: the build with the per-stage diagnostics (dr_stats_kernel_diag)
-  int pool_min_fill = 48;   // pool kernel: a wave takes a batch of a stage once this many paths wait for it
+  int pool_shade_min = 48;  // pool kernel: a wave shades once this many of its 128 paths wait for it
   unsigned* pool_scratch = nullptr; size_t pool_scratch_words_have = 0;
   int roles = 0;            // wide walk, long launches: 3 / 7 = workgroups of that many trace waves + one shade wave, 6 = 6 + 2 (render_roles_kernel)
   int paired = 0;           // wide walk, long launches: 1 = two paths per lane (render_paired_kernel: measured slower), 0 = the one-path kernel
@@ -239,7 +239,7 @@ bool use_pool(dr_context* c, const RenderParams& P) {
     if (hipMalloc((void**)&c->pool_scratch, need * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); c->pool_scratch = nullptr; return false; }
     c->pool_scratch_words_have = need;
   }
-  return ensure_abort_flag(c);
+  return true;
 }
 
 // path records of the experimental kernels for `waves` waves; false if the memory is not to be had
@@ -308,9 +308,8 @@ void enqueue_frame(dr_context* c, const RenderParams& P_in) {
     feedback_buffers(c, P, tiles, order, pcost);
     if (c->paired && enqueue_experimental(c, P, counter, order, pcost, fb)) {}
     else if (use_pool(c, P)) {
-      PoolCfg pc; pc.num_cus = c->num_cus; pc.min_fill = c->pool_min_fill; pc.diag = c->pool_diag != 0;
-      launch_pool_kernel(c->stream, P, pc, counter, order, order ? c->region_start : nullptr, pcost, c->pool_scratch, c->abort_flag);
-      c->abort_used = true;
+      PoolCfg pc; pc.num_cus = c->num_cus; pc.shade_min = c->pool_shade_min; pc.diag = c->pool_diag != 0;
+      launch_pool_kernel(c->stream, P, pc, counter, order, order ? c->region_start : nullptr, pcost, c->pool_scratch);
       c->wave_log_waves = 0;
     } else {
       if (!c->wave_log_on) P.wave_log = nullptr;
@@ -356,7 +355,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "coop_tiles_per_wave") { if (v < 0) goto bad; c->coop_tiles_per_wave = v; }
   else if (name == "paired") { c->paired = v != 0; }
   else if (name == "pool") { if (v < 0 || v > 2) goto bad; c->pool = v; }
-  else if (name == "pool_min_fill") { if (v < 1 || v > 64) goto bad; c->pool_min_fill = v; }
+  else if (name == "pool_shade_min") { if (v < 1 || v > 128) goto bad; c->pool_shade_min = v; }
   else if (name == "pool_diag") { c->pool_diag = v != 0; }
   else if (name == "roles") { if (v != 0 && v != 3 && v != 6 && v != 7) goto bad; c->roles = v; }
   else if (name == "pair_thresh") { if (v != 32 && v != 48 && v != 56) goto bad; c->pair_thresh = v; }
@@ -556,7 +555,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
   else if (n == "paired") *value = c->paired;
   else if (n == "pool") *value = c->pool;
-  else if (n == "pool_min_fill") *value = c->pool_min_fill;
+  else if (n == "pool_shade_min") *value = c->pool_shade_min;
   else if (n == "pool_diag") *value = c->pool_diag;
   else if (n == "experimental") *value = experimental_built() ? 1 : 0;
   else if (n == "roles") *value = c->roles;

@@ -1,6 +1,6 @@
 // Launchers of the device code, one translation unit per family of kernels:
 //   kernels_render.hip        the per-tile kernel (reference launch shape) and the persistent kernel (waves as pools of 64 path slots)
-//   kernels_pool.hip          the pool kernel: a workgroup-wide pool of paths in LDS, stages (node / leaf / shade) run at full width
+//   kernels_pool.hip          the pool kernel: every wave owns 128 paths in LDS and runs one kind of step (node / leaf / shade) at a time, at full width
 //   kernels_aux.hip           tile-order feedback, present divide, stripe copies of the multi-GPU gather, gather probe, known-answer kernels
 //   kernels_experimental.hip  round 2's two measured-slower kernels (two paths per lane, waves with roles); only in
 //                             -DDOGERAY_EXPERIMENTAL builds (tools/exp_variant.sh), not in the product library
@@ -40,13 +40,13 @@ int launch_persistent_kernel(hipStream_t stream, const RenderParams& P, const Pe
 // kernels_pool.hip
 struct PoolCfg {
   int num_cus;
-  int min_fill;              // a wave takes a batch of a stage once this many paths wait for it (or nothing else can be done)
+  int shade_min;             // a wave shades once this many of its paths wait for it (or nothing else can be done)
   bool diag;                 // the build that counts batches, paths per batch and cycles per part of the loop (counters[16..])
 };
 constexpr int COUNTER_WORDS = 64;   // 64-bit words of a context's statistics buffer: [0, 8) ray counters, [8, 16) dr_stats.diag, [16, 48) kernel diagnostics
 bool pool_kernel_can_render(const RenderParams& P);       // the launch shapes the pool kernel covers (wide walk resident, one sample per pixel ...)
 void launch_pool_kernel(hipStream_t stream, const RenderParams& P, const PoolCfg& cfg, unsigned* tile_counter, const int* order,
-                        const int* region_start, unsigned* pixel_cost, unsigned* scratch, unsigned* abort_flag);
+                        const int* region_start, unsigned* pixel_cost, unsigned* scratch);
 size_t pool_scratch_words(int num_cus);                   // global scratch of a launch (stack overflow words), 32-bit words
 
 // kernels_aux.hip

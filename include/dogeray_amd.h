@@ -277,9 +277,8 @@ int dr_stats_reset(dr_context* c);
 int dr_stats_get(dr_context* c, dr_stats* out);
 
 /* Diagnostics of the pool kernel's counting build (option "pool_diag" = 1), summed over waves since dr_stats_reset, n <= 48 words:
- * [0..2] batches of the node / leaf / shade stage, [3..5] paths in those batches, [6] shader cycles spent choosing and claiming
- * batches (waiting included), [7..9] cycles inside the node / leaf / shade step, [10] cycles pushing, [11] polls that waited for a
- * fuller batch, [12] lost claims, [13] polls that found nothing. */
+ * [0..2] batches of the node / leaf / shade stage, [3..5] paths in those batches, [6] shader cycles spent choosing a stage and
+ * compacting its paths onto the lanes, [7..9] cycles inside the node / leaf / shade step. */
 int dr_stats_kernel_diag(dr_context* c, unsigned long long* out, int n);
 
 /* Timeline of the last SHORT persistent-kernel launch (fewer than coop_tiles_per_wave tiles per wave: one frame, a thin stripe;

@@ -645,10 +645,10 @@ def test_waves_with_roles_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tm
 
 
 def test_pool_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
-    """render_pool_kernel (kernels_pool.hip; the default for long launches, forced here with option "pool" = 2): paths live in a
-    workgroup-wide pool in LDS and node / leaf / shade steps run as batches taken from queues.  Every material, textures, spheres,
-    margins of the preview divisor, frames that are not multiples of 8, fuzzed scenes with coincident triangles, batch fill
-    thresholds from 1 to 64 -- frames identical to the oracle's."""
+    """render_pool_kernel (kernels_pool.hip; the default for long launches, forced here with option "pool" = 2): every wave owns 128
+    paths in LDS and runs one kind of step at a time for up to 64 of them.  Every material, textures, spheres, margins of the preview
+    divisor, frames that are not multiples of 8, fuzzed scenes with coincident triangles (deep trees: stack words in the global scratch),
+    shade thresholds from 1 to 128 -- frames identical to the oracle's."""
     from scene_fuzz import random_scene
     rng = np.random.default_rng(2024)
     names = ["synth_albedo.ppm", "synth_rough.ppm", "synth_env.ppm", "a.ppm"]
@@ -660,14 +660,14 @@ def test_pool_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
     cases += [(random_scene(rng, int(rng.integers(2, 900)), str(tmp_path / ("pool%d.rts" % k)), W=96, H=64, textures=names), synth["tex"], 96, 64, 1) for k in range(8)]
     ctx.set_option("pool", 2)
     try:
-        for fill in (48, 1, 64):
-            ctx.set_option("pool_min_fill", fill)
+        for fill in (48, 1, 128):
+            ctx.set_option("pool_shade_min", fill)
             for path, tex, W, H, div in cases:
                 g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, div, 777, spp=1, mode=2, kernel=1)      # (more samples per pixel go to the persistent kernel)
-                _assert_frames(g, r, "%s pool kernel, min fill %d" % (os.path.basename(path), fill))
+                _assert_frames(g, r, "%s pool kernel, shade_min %d" % (os.path.basename(path), fill))
     finally:
         ctx.set_option("pool", 1)
-        ctx.set_option("pool_min_fill", 48)
+        ctx.set_option("pool_shade_min", 48)
 
 
 def test_pool_kernel_batched_accumulation(dr, orc, ctx, synth):

@@ -47,7 +47,7 @@ for opts in (sys.argv[1:] or [""]):
             for k, name in enumerate(("node", "leaf", "shade")):
                 line += "      %-5s batches/frame %9.0f  fill %5.1f  cycles/batch in step %7.0f  share of wave life %4.1f%%\n" % (
                     name, b[k] / n, l[k] / max(1, b[k]), d[7 + k] / max(1, b[k]), 100.0 * d[7 + k] / max(1, life))
-            line += "      choosing+claiming %4.1f%% of wave life (%.0f cycles/batch), pushing %4.1f%% (%.0f cycles/batch); waits for a fuller batch %.2f/batch, lost claims %.2f/batch, empty polls %.2f/batch" % (
-                100.0 * d[6] / max(1, life), d[6] / max(1, sum(b)), 100.0 * d[10] / max(1, life), d[10] / max(1, sum(b)), d[11] / max(1, sum(b)), d[12] / max(1, sum(b)), d[13] / max(1, sum(b)))
+            line += "      choosing + compacting %4.1f%% of wave life (%.0f cycles/batch);  node step: state in registers after %.0f cycles, record after %.0f more, compute + write back %.0f" % (
+                100.0 * d[6] / max(1, life), d[6] / max(1, sum(b)), d[10] / max(1, b[0]), d[11] / max(1, b[0]), (d[7] - d[10] - d[11]) / max(1, b[0]))
     print(line, flush=True)
     for k, v in old.items(): ctx.set_option(k, v)
