@@ -16,9 +16,12 @@ of a region in launches of up to --batch frames (one work queue over all their t
 throughput); `single_frame_ms` is the same scene with ONE frame per launch, what the reference's
 present loop does (one CudaStarter call per displayed frame, K:2154-2224).
 
-N > 1 is launched by torch.distributed.run, one rank per GPU; the framebuffer is tiled by interleaved
-8-pixel block columns and gathered to rank 0 over RCCL every --gather-every frames (scaling: strong,
-the frame is fixed).  Prints ONE JSON line on rank 0.
+N > 1: the framebuffer is tiled by interleaved 8-pixel block columns, one rank per GPU, and gathered to
+rank 0 over RCCL every --gather-every frames (scaling: strong, the frame is fixed).  Started by
+torch.distributed.run (WORLD_SIZE set) it is one process per GPU over torch.distributed; started plainly
+(`python bench.py --gpus N`) it is ONE process whose N ranks are the library's own dr_group (a context and a
+host thread per GPU, ncclCommInitAll + ncclSend / grouped ncclRecv; csrc/group.cpp).  DOGERAY_GROUP_DEVICES=0,0
+rehearses that path on one GPU (peer copies instead of RCCL).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -137,6 +140,108 @@ def algorithmic_bytes(c, frames, W, H):
     return 32 * c["node_visits"] + 36 * c["prim_tests"] + 128 * c["shades"] + 4 * c["texels"] + 12 * W * H * frames
 
 
+def main_group(args):
+    """`python bench.py --gpus N` without a launcher: the N ranks are the library's dr_group -- one context and one host thread
+    per GPU in THIS process, stripes gathered to rank 0 by ncclSend / grouped ncclRecv on a second stream per rank (peer copies
+    when ranks share a device: DOGERAY_GROUP_DEVICES=0,0).  Same frames, same seeds, same JSON line as the one-GPU run."""
+    import numpy as np
+    import dogeray_amd as dr
+    N = args.gpus
+    env_dev = [int(x) for x in os.environ.get("DOGERAY_GROUP_DEVICES", "").split(",") if x.strip() != ""]
+    devices = [env_dev[r] if r < len(env_dev) else r for r in range(N)]
+    if args.batch <= 0:
+        args.batch = min(256, 32 * N)
+    if args.gather_every <= 0:
+        args.gather_every = args.batch
+    W, H = args.width, args.height
+    scene_path = ensure_scene(args.cache, args.verts, W, H)
+    t0 = time.time(); scene = dr.Scene.load(scene_path, ""); t_parse = time.time() - t0
+    t0 = time.time(); scene.build_bvh(); t_bvh = time.time() - t0
+    s = scene.settings()
+    ntris = scene.num_objects
+    grp = dr.Group(devices)
+    t0 = time.time(); grp.upload(scene); t_upload = time.time() - t0
+    mode = {"wide": dr.TRAVERSAL_WIDE, "ordered": dr.TRAVERSAL_ORDERED, "threaded": dr.TRAVERSAL_THREADED}[args.traversal]
+    ctxs = [grp.context(r) for r in range(N)]
+    for c in ctxs:
+        c.set_traversal(mode)
+        c.set_option("batch_frames", min(args.batch, 256))
+    st = dr.pack_settings13(s, 1, spp=1)
+    log("scene %s: %d triangles, parse %.1fs, BVH %.1fs, upload on %d ranks %.2fs; transport %s" % (
+        os.path.basename(scene_path), ntris, t_parse, t_bvh, N, t_upload, "rccl" if grp.uses_rccl else "copy"))
+    seed_base, seed_stride = 1, 1000003
+    grp.accum_reset(W, H)
+
+    def run_frames(first, count):     # returns when every rank's stream and the gather have drained (dr_group joins its threads)
+        grp.render_accumulate(st, W, H, s.background, seed_base + first * seed_stride, seed_stride, count, args.gather_every)
+
+    run_frames(0, args.warmup)
+    region_s, timed = [], None
+    for rep in range(max(1, args.repeats)):
+        for c in ctxs:
+            c.stats_reset()
+        t0 = time.perf_counter()
+        run_frames(args.warmup, args.steps)
+        dt = time.perf_counter() - t0
+        region_s.append(dt)
+        st_rep = [c.stats() for c in ctxs]
+        slowest = max(x["kernel_ms"] for x in st_rep)
+        if timed is None or slowest < timed[0]:
+            timed = (slowest, st_rep)
+    srt = sorted(region_s)
+    elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    # the assembled accumulator against one context rendering the whole frame: the same frames, bit for bit
+    grp.accum_reset(W, H)
+    run_frames(args.warmup, min(args.steps, 4))
+    assembled = grp.accum_read()
+    # rays: count what the timed frames traced, every rank its stripe
+    for c in ctxs:
+        c.enable_counters(True); c.stats_reset()
+    grp.accum_reset(W, H)
+    run_frames(args.warmup, args.steps)
+    counted = [c.stats() for c in ctxs]
+    for c in ctxs:
+        c.enable_counters(False)
+    rays = sum(x["rays"] for x in counted)
+    ranks_transport = grp.rccl_ranks
+    uses_rccl = grp.uses_rccl
+    grp.close()
+    whole = dr.Context(devices[0]).upload(scene)
+    whole.set_traversal(mode)
+    whole.accum_reset(W, H)
+    whole.render_accumulate(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, min(args.steps, 4))
+    identical = bool(np.array_equal(whole.accum_read(), assembled))
+    whole.close()
+    frames = args.steps
+    per_rank_ms = [x["kernel_ms"] for x in timed[1]]
+    result = {
+        "metric": "Mrays/sec + ms/frame, 1M-tri .rts at 1920x1080",
+        "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / frames * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {
+            "workload": "C4 stand-in for samples/highpoly.rts: heightfield %d triangles, %dx%d, 1 spp/frame, depth %d, %s traversal"
+                        % (ntris, W, H, s.max_depth, args.traversal),
+            "triangles": ntris, "width": W, "height": H, "spp_per_frame": 1, "max_depth": int(s.max_depth), "frames": frames,
+            "parallelism": "framebuffer block-column stripes x%d, one process (dr_group: a context and a host thread per GPU)" % N,
+            "gather_every": args.gather_every, "frames_per_launch": min(args.batch, 256, args.gather_every),
+        },
+        "launcher": "dr_group (in-process)",
+        "transport": "rccl" if uses_rccl else "copy",
+        "rccl_ranks": ranks_transport,
+        "devices": devices,
+        "assembled_frame_identical_to_one_context": identical,
+        "repeats": len(region_s), "ms_per_step_min": min(region_s) / frames * 1e3, "ms_per_step_max": max(region_s) / frames * 1e3,
+        "rays_per_frame": rays / frames, "primary_samples_per_s": (W * H * frames) / elapsed,
+        "kernel_ms_per_rank": per_rank_ms,
+        "setup_s": {"parse": t_parse, "bvh_build": t_bvh, "upload": t_upload},
+        "roofline": None, "cpu_baseline": None,
+        "note": "roofline and cpu_baseline are reported by the one-GPU run (same kernels; N = 1 is the configuration the metric is quoted on)",
+    }
+    print(json.dumps(result), flush=True)
+    return 0 if identical else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -159,10 +264,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return main_group(args)          # one process, N ranks inside the library (dr_group)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            log("bench.py: --gpus %d needs torch.distributed.run with %d ranks" % (args.gpus, args.gpus))
-            sys.exit(2)
         args.gpus = world
 
     if args.batch <= 0:
@@ -292,6 +396,31 @@ def main():
         st1 = ctx.stats()
         single = {"kernel_ms": st1["kernel_ms"] / max(1, st1["frames"]), "wall_ms": wall1 / n1 * 1e3, "frames": n1,
                   "launches": st1["launches"]}
+        # the same one-frame launches through the pipeline (frame k + 1 starts while frame k drains; per-frame buffers added in order),
+        # without and with the display divide + download of every frame (what an interactive viewer pays)
+        try:
+            n2 = max(n1, 32)
+            ctx._acc_shape = (W, H, 3)
+            ctx.render_accumulate_pipelined(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, 8)
+            walls = []
+            for rep in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.render_accumulate_pipelined(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, n2)
+                walls.append((time.perf_counter() - t0) / n2 * 1e3)
+            single["pipelined_wall_ms"] = sorted(walls)[1]
+            t0 = time.perf_counter()
+            pend = []
+            for k in range(n2):
+                pend.append(ctx.pipeline_submit(st, W, H, s.background, seed_base + (args.warmup + k) * seed_stride, k + 1))
+                if len(pend) == 2:
+                    ctx.pipeline_wait(pend.pop(0), want_image=True)
+            for t in pend:
+                ctx.pipeline_wait(t, want_image=True)
+            single["pipelined_present_wall_ms"] = (time.perf_counter() - t0) / n2 * 1e3
+            single["pipelined_frames"] = n2
+        except Exception as e:
+            log("pipelined single frames failed: %r" % (e,))
         ctx.set_option("batch_frames", min(args.batch, 256))
 
     # ---- gather ceiling of this GPU on the resident walk array (roofline.gather)
@@ -365,6 +494,7 @@ def main():
         "ms_per_step_min": min(region_s) / frames * 1e3,
         "ms_per_step_max": max(region_s) / frames * 1e3,
         "single_frame_ms": single["kernel_ms"] if single else None,
+        "single_frame_pipelined_ms": single.get("pipelined_wall_ms") if single else None,
         "single_frame": single,
         "rays_per_frame": rays / frames,
         "primary_samples_per_s": (W * H * frames) / elapsed,
@@ -475,4 +605,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

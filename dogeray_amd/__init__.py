@@ -104,6 +104,9 @@ _API = [
     ("dr_accum_device_ptr", C.c_int, [_VP, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
     ("dr_render_accumulate_async", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_int]),
     ("dr_context_synchronize", C.c_int, [_VP]),
+    ("dr_pipeline_submit", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
+    ("dr_pipeline_wait", C.c_int, [_VP, C.c_uint64, _VP]),
+    ("dr_render_accumulate_pipelined", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_int]),
     ("dr_context_stream", C.c_int, [_VP, C.POINTER(_VP)]),
     ("dr_accum_pack_stripe", C.c_int, [_VP, C.c_int, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
     ("dr_accum_unpack_stripes", C.c_int, [_VP, _VP, C.c_uint64, C.c_int, C.c_int, _VP]),
@@ -340,6 +343,28 @@ class Context:
         st = _f32(settings13)
         _check(lib().dr_render_accumulate_async(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1),
                                                 int(seed_stride) & (2 ** 64 - 1), nframes))
+
+    def pipeline_submit(self, settings13, W, H, background, frame_seed, present_divide_by=0):
+        """Queues one frame of the pipelined present loop (dr_pipeline_submit); returns its ticket."""
+        st = _f32(settings13)
+        t = C.c_uint64(0)
+        _check(lib().dr_pipeline_submit(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1), int(present_divide_by), C.byref(t)))
+        return int(t.value)
+
+    def pipeline_wait(self, ticket, want_image=False):
+        """Waits for a submitted frame; with want_image the RGB8 image [H, W, 3] of exactly the frames up to that ticket."""
+        if not want_image:
+            _check(lib().dr_pipeline_wait(self._h, int(ticket), None))
+            return None
+        W, H, _ = self._acc_shape
+        img = np.empty((H, W, 3), dtype=np.uint8)
+        _check(lib().dr_pipeline_wait(self._h, int(ticket), _p(img)))
+        return img
+
+    def render_accumulate_pipelined(self, settings13, W, H, background, frame_seed, seed_stride, nframes):
+        st = _f32(settings13)
+        _check(lib().dr_render_accumulate_pipelined(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1),
+                                                    int(seed_stride) & (2 ** 64 - 1), nframes))
 
     def synchronize(self):
         _check(lib().dr_context_synchronize(self._h))
@@ -589,3 +614,27 @@ class ProgressiveRenderer:
 
     def image(self, divide_by):
         return self.ctx.accum_present(divide_by)
+
+    def run_pipelined(self, nframes, on_image=None):
+        """The accumulating part of the loop (iter >= 4), `nframes` frames, pipelined (dr_pipeline_submit / dr_pipeline_wait): frame k + 1
+        is queued before frame k's image is waited for.  on_image(iter, divide_by, rgb[H, W, 3]) gets every displayed image, each exactly
+        clamp(sum of the frames so far / divide_by, 0, 255)."""
+        assert self.iter >= 4, "run the preview ladder (four step() calls) first"
+        s, c = self.s, self.ctx
+        c._acc_shape = (self.W, self.H, 3)
+        st = pack_settings13(s, 1)
+        pending = []
+        for k in range(nframes):
+            self.iter += 1
+            div = self.iter - 3
+            pending.append((c.pipeline_submit(st, self.W, self.H, s.background, self._seed(), div), self.iter, div))
+            self.frames_rendered += 1
+            if len(pending) == 2:
+                t, it, dv = pending.pop(0)
+                img = c.pipeline_wait(t, want_image=True)
+                if on_image:
+                    on_image(it, dv, img)
+        for t, it, dv in pending:
+            img = c.pipeline_wait(t, want_image=True)
+            if on_image:
+                on_image(it, dv, img)

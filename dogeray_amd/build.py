@@ -36,6 +36,7 @@ def build(force=False, verbose=False):
     objs = []
     hipcc = _hipcc()
     os.makedirs(os.path.join(HERE, "_build"), exist_ok=True)
+    cmds = []
     for src in HOST_SOURCES + DEVICE_SOURCES:
         sp = os.path.join(CSRC, src)
         obj = os.path.join(HERE, "_build", src + ".o")
@@ -51,9 +52,16 @@ def build(force=False, verbose=False):
             cmd = [hipcc] + COMMON + slp + sched + ["--offload-arch=" + ARCH, "-c", sp, "-o", obj]
             if src.endswith(".cpp"):
                 cmd = [hipcc] + COMMON + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c", sp, "-o", obj]
+            cmds.append(cmd)
+    if cmds:      # the translation units are independent: compile them side by side
+        from concurrent.futures import ThreadPoolExecutor
+
+        def run(cmd):
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.check_call(cmd)
+        with ThreadPoolExecutor(max_workers=min(len(cmds), max(1, (os.cpu_count() or 2) // 2))) as ex:
+            list(ex.map(run, cmds))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs + ["-pthread", "-ldl"]
         if verbose:

@@ -43,8 +43,9 @@ struct dr_context {
   void* paths = nullptr; size_t paths_waves = 0;        // experimental kernels: path records in global memory (16-byte units)
   unsigned* abort_flag = nullptr;                        // experimental roles kernel: set by a wave that waited too long (protocol failure)
   bool abort_used = false;                               // a launch that may set it has been queued since the last check
-  int pool = 1;             // wide walk: 1 = long launches run the pool kernel (kernels_pool.hip), 2 = every launch it can render, 0 = never (persistent kernel)
+  int pool = 0;             // -DDOGERAY_EXPERIMENTAL builds, wide walk: 1 = long launches run the pool kernel (kernels_pool.hip: measured slower), 2 = every launch it can render, 0 = never
   int pool_diag = 0;        // pool kernel: the build with the per-stage diagnostics (dr_stats_kernel_diag)
+  int pool_shape = 0;       // pool kernel: 0 = 4 stack words per path in LDS and 15 waves per CU, 1 = 3 words and 16 waves, 2 = 8 words and 12 waves
   int pool_shade_min = 48;  // pool kernel: a wave shades once this many of its 128 paths wait for it
   unsigned* pool_scratch = nullptr; size_t pool_scratch_words_have = 0;
   int roles = 0;            // wide walk, long launches: 3 / 7 = workgroups of that many trace waves + one shade wave, 6 = 6 + 2 (render_roles_kernel)
@@ -85,6 +86,27 @@ struct dr_context {
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
   float cur_settings[13] = {0};
   dr_stats stats;
+  // pipelined single frames (dr_pipeline_*): a second render stream, a stream that folds finished frames into the accumulator in
+  // frame order, and PIPE_DEPTH frame buffers / present buffers that rotate
+  static constexpr int PIPE_STREAMS = 4;           // render streams (stream itself is number 0); option pipe_streams uses 2 .. 4 of them
+  static constexpr int PIPE_DEPTH = PIPE_STREAMS + 1;
+  int pipe_streams = 2;     // render streams the pipeline alternates between
+  int pipe_lean = 0;        // pipelined launches run the lean build with one queue per XCD instead of the work-sharing build (their tails overlap other frames)
+  hipStream_t pipe_stream[PIPE_STREAMS] = {nullptr, nullptr, nullptr, nullptr}, acc_stream = nullptr;      // pipe_stream[0] = stream
+  int32_t* pipe_frame[PIPE_DEPTH] = {nullptr}; size_t pipe_elems[PIPE_DEPTH] = {0};
+  int pipe_rect[PIPE_DEPTH][6] = {{0}};            // W, H, gx, gy, stripe mod, stripe rem the buffer was last rendered with (its margins are 0)
+  hipEvent_t pipe_rendered[PIPE_DEPTH] = {nullptr}, pipe_added[PIPE_DEPTH] = {nullptr};
+  uint8_t* pipe_rgb_dev[PIPE_DEPTH] = {nullptr}; uint8_t* pipe_rgb_host[PIPE_DEPTH] = {nullptr};
+  size_t pipe_rgb_bytes[PIPE_DEPTH] = {0};
+  int pipe_div[PIPE_DEPTH] = {0};                  // divisor the slot's frame was presented with (0: not presented)
+  bool pipe_waited[PIPE_DEPTH] = {true, true, true, true, true};
+  uint64_t pipe_next = 0;                          // ticket of the next frame
+  hipEvent_t pipe_last[PIPE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};    // end of the newest launch on each render stream
+  bool pipe_last_set[PIPE_STREAMS] = {false, false, false, false};
+  hipEvent_t pipe_barrier = nullptr; bool pipe_barrier_set = false;      // end of the newest tile-order refresh: later launches read that order
+  hipEvent_t pipe_sync = nullptr;                  // orders the pipeline after earlier work on `stream`
+  bool pipe_dirty = false;                         // frames have gone through the pipeline since the last join
+  bool pipe_hold_order = false;                    // enqueue_frame: use the stored tile order as it is, record no costs (a launch beside another one)
 };
 
 namespace {
@@ -232,7 +254,7 @@ bool ensure_abort_flag(dr_context* c);
 inline bool long_launch(const dr_context* c, const RenderParams& P);
 // the pool kernel renders this launch: wide walk resident, a long launch, the non-counting build, and its buffers are to be had
 bool use_pool(dr_context* c, const RenderParams& P) {
-  if (!c->pool || c->count || traversal_of(c) != DR_TRAVERSAL_WIDE || !pool_kernel_can_render(P) || (c->pool == 1 && !long_launch(c, P))) return false;
+  if (!c->pool || !experimental_built() || c->count || traversal_of(c) != DR_TRAVERSAL_WIDE || !pool_kernel_can_render(P) || (c->pool == 1 && !long_launch(c, P))) return false;
   const size_t need = pool_scratch_words(c->num_cus);
   if (c->pool_scratch_words_have < need) {
     if (c->pool_scratch) { (void)hipFree(c->pool_scratch); c->pool_scratch = nullptr; c->pool_scratch_words_have = 0; }
@@ -305,10 +327,15 @@ void enqueue_frame(dr_context* c, const RenderParams& P_in) {
     bool fb = false;
     if (c->roles && enqueue_experimental(c, P, counter, nullptr, nullptr, fb)) return;
     const int* order; unsigned* pcost;
-    feedback_buffers(c, P, tiles, order, pcost);
+    if (c->pipe_hold_order) {
+      // a pipelined launch runs beside the previous frame's: it may read the tile order but nobody may write it (or the costs) meanwhile
+      const float geom[5] = {(float)P.W, (float)P.H, (float)(P.stripe_mod * 1024 + P.stripe_rem) + 0.125f * (float)P.regions, (float)P.ncols, (float)P.gy};
+      order = (c->order_valid && c->order_capacity >= tiles && memcmp(c->order_key + 13, geom, sizeof(geom)) == 0) ? c->tile_order : nullptr;
+      pcost = nullptr;
+    } else feedback_buffers(c, P, tiles, order, pcost);
     if (c->paired && enqueue_experimental(c, P, counter, order, pcost, fb)) {}
     else if (use_pool(c, P)) {
-      PoolCfg pc; pc.num_cus = c->num_cus; pc.shade_min = c->pool_shade_min; pc.diag = c->pool_diag != 0;
+      PoolCfg pc; pc.num_cus = c->num_cus; pc.shade_min = c->pool_shade_min; pc.shape = c->pool_shape; pc.diag = c->pool_diag != 0;
       launch_pool_kernel(c->stream, P, pc, counter, order, order ? c->region_start : nullptr, pcost, c->pool_scratch);
       c->wave_log_waves = 0;
     } else {
@@ -329,6 +356,8 @@ void enqueue_frame(dr_context* c, const RenderParams& P_in) {
   }
   launch_tile_kernel(c->stream, P, traversal_of(c), c->count, c->occupancy);
 }
+
+int join_pipeline(dr_context* c);
 
 int set_option(dr_context* c, const std::string& name, int v) {
   if (name == "kernel") { if (v != DR_KERNEL_TILE && v != DR_KERNEL_PERSISTENT) goto bad; c->kernel = v; }
@@ -357,6 +386,16 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "pool") { if (v < 0 || v > 2) goto bad; c->pool = v; }
   else if (name == "pool_shade_min") { if (v < 1 || v > 128) goto bad; c->pool_shade_min = v; }
   else if (name == "pool_diag") { c->pool_diag = v != 0; }
+  else if (name == "pipe_streams") {
+    if (v < 2 || v > dr_context::PIPE_STREAMS) goto bad;
+    if (v != c->pipe_streams) {               // slots and streams are numbered by ticket: drain, then start again from ticket 0
+      if (hipSetDevice(c->device) != hipSuccess || join_pipeline(c) != DR_OK || hipStreamSynchronize(c->stream) != hipSuccess) { set_error("pipe_streams: cannot drain the pipeline"); return DR_ERR_DEVICE; }
+      for (int k = 0; k < dr_context::PIPE_DEPTH; k++) c->pipe_waited[k] = true;
+      c->pipe_next = 0; c->pipe_streams = v;
+    }
+  }
+  else if (name == "pipe_lean") { c->pipe_lean = v != 0; }
+  else if (name == "pool_shape") { if (v < 0 || v > 2) goto bad; c->pool_shape = v; }
   else if (name == "roles") { if (v != 0 && v != 3 && v != 6 && v != 7) goto bad; c->roles = v; }
   else if (name == "pair_thresh") { if (v != 32 && v != 48 && v != 56) goto bad; c->pair_thresh = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
@@ -400,6 +439,30 @@ int collect_time(dr_context* c, uint64_t frames, uint64_t samples) {
   c->stats.kernel_ms += ms;
   c->stats.frames += frames;
   c->stats.samples += samples;
+  return DR_OK;
+}
+
+// Work queued through the pipeline runs on two more streams: everything else (which uses `stream`) is ordered behind it here.
+int join_pipeline(dr_context* c) {
+  if (!c->pipe_dirty) return DR_OK;
+  for (int k = 0; k < dr_context::PIPE_DEPTH; k++)
+    if (c->pipe_added[k]) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_added[k], 0));
+  for (int k = 1; k < dr_context::PIPE_STREAMS; k++) if (c->pipe_last_set[k]) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_last[k], 0));
+  c->pipe_dirty = false;
+  return DR_OK;
+}
+
+int pipeline_setup(dr_context* c) {
+  if (c->acc_stream) return DR_OK;
+  bool ok = hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking) == hipSuccess;
+  c->pipe_stream[0] = c->stream;
+  for (int k = 1; k < dr_context::PIPE_STREAMS; k++) ok = ok && hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking) == hipSuccess;
+  if (!ok) { set_error("pipeline: cannot create streams"); return DR_ERR_DEVICE; }
+  for (int k = 0; k < dr_context::PIPE_DEPTH; k++)
+    ok = ok && hipEventCreateWithFlags(&c->pipe_rendered[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->pipe_added[k], hipEventDisableTiming) == hipSuccess;
+  for (int k = 0; k < dr_context::PIPE_STREAMS; k++) ok = ok && hipEventCreateWithFlags(&c->pipe_last[k], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->pipe_barrier, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->pipe_sync, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { set_error("pipeline: cannot create events"); return DR_ERR_DEVICE; }
   return DR_OK;
 }
 
@@ -481,6 +544,18 @@ void dr_context_destroy(dr_context* c) {
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int k = 0; k < 2; k++) { if (c->pev0[k]) (void)hipEventDestroy(c->pev0[k]); if (c->pev1[k]) (void)hipEventDestroy(c->pev1[k]); }
+  for (int k = 1; k < dr_context::PIPE_STREAMS; k++) if (c->pipe_stream[k]) (void)hipStreamSynchronize(c->pipe_stream[k]);
+  if (c->acc_stream) (void)hipStreamSynchronize(c->acc_stream);
+  for (int k = 0; k < dr_context::PIPE_DEPTH; k++) {
+    if (c->pipe_frame[k]) (void)hipFree(c->pipe_frame[k]);
+    if (c->pipe_rgb_dev[k]) (void)hipFree(c->pipe_rgb_dev[k]);
+    if (c->pipe_rgb_host[k]) (void)hipHostFree(c->pipe_rgb_host[k]);
+    if (c->pipe_rendered[k]) (void)hipEventDestroy(c->pipe_rendered[k]);
+    if (c->pipe_added[k]) (void)hipEventDestroy(c->pipe_added[k]);
+  }
+  for (hipEvent_t e : {c->pipe_last[0], c->pipe_last[1], c->pipe_last[2], c->pipe_last[3], c->pipe_barrier, c->pipe_sync}) if (e) (void)hipEventDestroy(e);
+  for (int k = 1; k < dr_context::PIPE_STREAMS; k++) if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
+  if (c->acc_stream) (void)hipStreamDestroy(c->acc_stream);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
 }
@@ -557,6 +632,9 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "pool") *value = c->pool;
   else if (n == "pool_shade_min") *value = c->pool_shade_min;
   else if (n == "pool_diag") *value = c->pool_diag;
+  else if (n == "pipe_streams") *value = c->pipe_streams;
+  else if (n == "pipe_lean") *value = c->pipe_lean;
+  else if (n == "pool_shape") *value = c->pool_shape;
   else if (n == "experimental") *value = experimental_built() ? 1 : 0;
   else if (n == "roles") *value = c->roles;
   else if (n == "pair_thresh") *value = c->pair_thresh;
@@ -583,6 +661,7 @@ int dr_render_frame(dr_context* c, const float settings13[13], int W, int H, flo
                     int32_t* out_int3) {
   if (!c || !settings13) { set_error("null argument"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
+  { const int jrc = join_pipeline(c); if (jrc != DR_OK) return jrc; }
   RenderParams P;
   int rc = make_params(c, settings13, W, H, background, frame_seed, P);
   if (rc != DR_OK) return rc;
@@ -606,6 +685,7 @@ int dr_render_frame(dr_context* c, const float settings13[13], int W, int H, flo
 int dr_accum_reset(dr_context* c, int W, int H) {
   if (!c || W <= 0 || H <= 0) { set_error("bad argument"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
+  { const int jrc = join_pipeline(c); if (jrc != DR_OK) return jrc; }
   size_t elems = (size_t)W * H * 3;
   int rc = ensure(c->accum, c->accum_elems, elems);
   if (rc != DR_OK) return rc;
@@ -625,6 +705,7 @@ int accumulate_enqueue(dr_context* c, const float settings13[13], int W, int H, 
   if (!c || !settings13 || nframes < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
   if (!c->accum || c->accW != W || c->accH != H) { set_error("call dr_accum_reset(W, H) first"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
+  { const int jrc = join_pipeline(c); if (jrc != DR_OK) return jrc; }
   RenderParams P;
   const int per = (uses_persistent(c) && c->batch_frames > 1) ? c->batch_frames : 1;
   int rc = make_params(c, settings13, W, H, background, frame_seed, P, nframes < per ? nframes : per);
@@ -698,11 +779,141 @@ int dr_render_accumulate_async(dr_context* c, const float settings13[13], int W,
 int dr_context_synchronize(dr_context* c) {
   if (!c) { set_error("null context"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
+  { const int jrc = join_pipeline(c); if (jrc != DR_OK) return jrc; }
   int rc;
   if ((rc = collect_pending(c, c->pending_next)) != DR_OK) return rc;       // older first
   if ((rc = collect_pending(c, c->pending_next ^ 1)) != DR_OK) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
   return check_abort(c);
+}
+
+int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed, int present_divide_by,
+                       uint64_t* ticket) {
+  if (!c || !settings13) { set_error("null argument"); return DR_ERR_INVALID; }
+  if (!c->accum || c->accW != W || c->accH != H) { set_error("call dr_accum_reset(W, H) first"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = pipeline_setup(c);
+  if (rc != DR_OK) return rc;
+  RenderParams P;
+  // (pipe_lean: the lean six-wave build and one queue per XCD, as for long launches -- the tail it leaves runs beside the next frames)
+  const int saved_ctpw = c->coop_tiles_per_wave;
+  if (c->pipe_lean) c->coop_tiles_per_wave = 0;
+  rc = make_params(c, settings13, W, H, background, frame_seed, P, 1);
+  c->coop_tiles_per_wave = saved_ctpw;
+  if (rc != DR_OK) return rc;
+  if (c->traversal == DR_TRAVERSAL_ORDERED && c->tree_depth > ORDERED_STACK) { set_error("tree too deep for ordered traversal"); return DR_ERR_SCENE; }
+  const uint64_t k = c->pipe_next;
+  const int nstreams = c->pipe_streams, depth = nstreams + 1;
+  const int slot = (int)(k % (uint64_t)depth), si = (int)(k % (uint64_t)nstreams);
+  hipStream_t rs = c->pipe_stream[si];
+  const size_t elems = (size_t)W * H * 3;
+  if (!c->pipe_dirty) {                       // the first frame after other work: the pipeline's streams start behind it
+    HIP_TRY(hipEventRecord(c->pipe_sync, c->stream));
+    for (int q = 1; q < dr_context::PIPE_STREAMS; q++) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[q], c->pipe_sync, 0));
+    HIP_TRY(hipStreamWaitEvent(c->acc_stream, c->pipe_sync, 0));
+    c->pipe_dirty = true;
+  }
+  // the slot's previous frame (ticket k - PIPE_DEPTH): its present buffer goes back to the caller first, and its add must have run
+  if (!c->pipe_waited[slot]) { HIP_TRY(hipEventSynchronize(c->pipe_added[slot])); c->pipe_waited[slot] = true; }
+  if (k >= (uint64_t)depth) HIP_TRY(hipStreamWaitEvent(rs, c->pipe_added[slot], 0));
+  if (c->pipe_elems[slot] < elems || !c->pipe_frame[slot]) {
+    if (c->pipe_frame[slot]) { HIP_TRY(hipStreamSynchronize(c->acc_stream)); (void)hipFree(c->pipe_frame[slot]); c->pipe_frame[slot] = nullptr; c->pipe_elems[slot] = 0; }
+    HIP_TRY(hipMalloc((void**)&c->pipe_frame[slot], elems * sizeof(int32_t)));
+    c->pipe_elems[slot] = elems;
+    c->pipe_rect[slot][0] = -1;
+  }
+  // pixels outside the rendered block grid are 0 (K:2633-2636): the buffer is cleared when that grid changes, every frame of a grid
+  // overwrites the same pixels
+  const int rect[6] = {W, H, P.gx, P.gy, P.stripe_mod, P.stripe_rem};
+  if (memcmp(rect, c->pipe_rect[slot], sizeof(rect)) != 0) {
+    HIP_TRY(hipMemsetAsync(c->pipe_frame[slot], 0, elems * sizeof(int32_t), rs));
+    memcpy(c->pipe_rect[slot], rect, sizeof(rect));
+  }
+  P.out = c->pipe_frame[slot];
+  P.accumulate = 0;
+  const int tiles = P.ncols * P.gy;
+  // the tile order and the costs it is made from are shared by all launches: a launch that refreshes them runs alone (after the other
+  // stream's newest launch, and the launches after it wait for the refresh); all others read the order as it is
+  bool refresh = false;
+  if (c->feedback && uses_persistent(c) && tiles > 0) {
+    const float geom[5] = {(float)P.W, (float)P.H, (float)(P.stripe_mod * 1024 + P.stripe_rem) + 0.125f * (float)P.regions, (float)P.ncols, (float)P.gy};
+    // (a refresh costs the overlap of two frames, 0.89 against 0.82 ms/frame when every 8th launch refreshes: four times rarer here)
+    refresh = !c->order_valid || c->order_capacity < tiles || memcmp(c->order_key + 13, geom, sizeof(geom)) != 0 || c->order_age < 2 ||
+              c->order_age % (4 * c->feedback_every) == 0;
+  }
+  if (c->pipe_barrier_set) HIP_TRY(hipStreamWaitEvent(rs, c->pipe_barrier, 0));
+  if (refresh || c->tile_cursor + MAX_REGIONS > TILE_COUNTERS)
+    for (int q = 0; q < dr_context::PIPE_STREAMS; q++) if (q != si && c->pipe_last_set[q]) HIP_TRY(hipStreamWaitEvent(rs, c->pipe_last[q], 0));
+  if (tiles > 0) {
+    hipStream_t saved = c->stream;
+    c->stream = rs; c->pipe_hold_order = !refresh;
+    if (c->pipe_lean) c->coop_tiles_per_wave = 0;
+    enqueue_frame(c, P);
+    c->stream = saved; c->pipe_hold_order = false; c->coop_tiles_per_wave = saved_ctpw;
+    HIP_TRY(hipGetLastError());
+  }
+  HIP_TRY(hipEventRecord(c->pipe_last[si], rs)); c->pipe_last_set[si] = true;
+  if (refresh) { HIP_TRY(hipEventRecord(c->pipe_barrier, rs)); c->pipe_barrier_set = true; }
+  HIP_TRY(hipEventRecord(c->pipe_rendered[slot], rs));
+  // fold into the accumulator, in ticket order (K:2213-2218), and make the image of exactly the frames so far (K:2287)
+  HIP_TRY(hipStreamWaitEvent(c->acc_stream, c->pipe_rendered[slot], 0));
+  launch_frame_add(c->acc_stream, c->accum, c->pipe_frame[slot], elems);
+  c->pipe_div[slot] = 0;
+  if (present_divide_by != 0) {
+    const size_t bytes = (size_t)W * H * 3;
+    if (c->pipe_rgb_bytes[slot] < bytes) {
+      HIP_TRY(hipStreamSynchronize(c->acc_stream));
+      if (c->pipe_rgb_dev[slot]) (void)hipFree(c->pipe_rgb_dev[slot]);
+      if (c->pipe_rgb_host[slot]) (void)hipHostFree(c->pipe_rgb_host[slot]);
+      c->pipe_rgb_dev[slot] = nullptr; c->pipe_rgb_host[slot] = nullptr; c->pipe_rgb_bytes[slot] = 0;
+      HIP_TRY(hipMalloc((void**)&c->pipe_rgb_dev[slot], bytes));
+      HIP_TRY(hipHostMalloc((void**)&c->pipe_rgb_host[slot], bytes, hipHostMallocDefault));
+      c->pipe_rgb_bytes[slot] = bytes;
+    }
+    launch_present(c->acc_stream, c->accum, c->pipe_rgb_dev[slot], W, H, present_divide_by);
+    HIP_TRY(hipMemcpyAsync(c->pipe_rgb_host[slot], c->pipe_rgb_dev[slot], bytes, hipMemcpyDeviceToHost, c->acc_stream));
+    c->pipe_div[slot] = present_divide_by;
+  }
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(c->pipe_added[slot], c->acc_stream));
+  c->pipe_waited[slot] = false;
+  c->pipe_next = k + 1;
+  c->stats.launches += tiles > 0 ? 1 : 0;
+  c->stats.frames += 1;
+  c->stats.samples += (uint64_t)(tiles > 0 ? tiles : 0) * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0);
+  if (ticket) *ticket = k;
+  return DR_OK;
+}
+
+int dr_pipeline_wait(dr_context* c, uint64_t ticket, uint8_t* out_rgb8) {
+  if (!c || !c->acc_stream) { set_error("pipeline: nothing submitted"); return DR_ERR_INVALID; }
+  const uint64_t depth = (uint64_t)c->pipe_streams + 1;
+  if (ticket >= c->pipe_next || ticket + depth < c->pipe_next) { set_error("pipeline: ticket not in flight (the pipeline keeps pipe_streams + 1 frames)"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  const int slot = (int)(ticket % depth);
+  HIP_TRY(hipEventSynchronize(c->pipe_added[slot]));
+  c->pipe_waited[slot] = true;
+  if (out_rgb8) {
+    if (!c->pipe_div[slot]) { set_error("pipeline: that frame was submitted without a present"); return DR_ERR_INVALID; }
+    memcpy(out_rgb8, c->pipe_rgb_host[slot], (size_t)c->accW * c->accH * 3);
+  }
+  return DR_OK;
+}
+
+int dr_render_accumulate_pipelined(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
+                                   uint64_t seed_stride, int nframes) {
+  if (!c || nframes < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  uint64_t last = 0;
+  for (int k = 0; k < nframes; k++) {
+    const int rc = dr_pipeline_submit(c, settings13, W, H, background, frame_seed + (uint64_t)k * seed_stride, 0, &last);
+    if (rc != DR_OK) return rc;
+  }
+  if (nframes > 0) {
+    const int rc = dr_pipeline_wait(c, last, nullptr);      // adds run in order: the last one ends the batch
+    if (rc != DR_OK) return rc;
+    for (int k = 0; k < dr_context::PIPE_DEPTH; k++) c->pipe_waited[k] = true;
+  }
+  return DR_OK;
 }
 
 int dr_context_stream(dr_context* c, void** hip_stream) {
@@ -725,6 +936,7 @@ int dr_accum_reserve_pack(dr_context* c, int slot) {
 int dr_accum_pack_stripe(dr_context* c, int slot, void** dev_ptr, uint64_t* bytes) {
   if (!c || !c->accum || (slot != 0 && slot != 1)) { set_error("pack: no accumulator, or slot not 0/1"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
+  { const int jrc = join_pipeline(c); if (jrc != DR_OK) return jrc; }
   const int gx = c->accW / 8;
   const int ncols = gx > c->stripe_rem ? (gx - c->stripe_rem + c->stripe_mod - 1) / c->stripe_mod : 0;
   const size_t run = (size_t)8 * (size_t)c->accH * 3;                 // int32 per block column
@@ -763,6 +975,7 @@ int dr_accum_unpack_stripes(dr_context* c, const void* packed_dev, uint64_t rank
 int dr_accum_read(dr_context* c, int32_t* out_int3) {
   if (!c || !out_int3 || !c->accum) { set_error("no accumulator"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
+  { const int jrc = join_pipeline(c); if (jrc != DR_OK) return jrc; }
   HIP_TRY(hipMemcpyAsync(out_int3, c->accum, (size_t)c->accW * c->accH * 3 * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return DR_OK;
@@ -771,6 +984,7 @@ int dr_accum_read(dr_context* c, int32_t* out_int3) {
 int dr_accum_present(dr_context* c, int divide_by, uint8_t* out_rgb8) {
   if (!c || !out_rgb8 || !c->accum || divide_by == 0) { set_error("bad argument"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
+  { const int jrc = join_pipeline(c); if (jrc != DR_OK) return jrc; }
   size_t bytes = (size_t)c->accW * c->accH * 3;
   if (c->present_bytes < bytes) {
     if (c->present) (void)hipFree(c->present);

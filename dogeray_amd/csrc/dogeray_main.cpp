@@ -186,6 +186,32 @@ int main(int argc, char** argv) {
       pack13(s, ladder[iter], iter == 0 ? s.spp : 1, iter == 0 ? s.max_depth : 2, st);
       if (reset() != DR_OK) die("reset");                            // CudaStarter overwrites outr on these calls
       pnum = iter;
+    } else if (!grp && group == 1) {
+      // one frame per present, as the reference does it -- but pipelined: frame k + 1 is queued before frame k's image is waited for, so
+      // its launch starts while frame k's slowest pixels drain; every image is still exactly clamp(sum of the frames so far / count)
+      pack13(s, 1, s.spp, s.max_depth, st);
+      uint64_t tickets[2]; int divs[2]; int inflight = 0;
+      auto t_prev = std::chrono::steady_clock::now();
+      while (iter < total_iters || inflight > 0) {
+        if (iter < total_iters && inflight < 2) {
+          iter++;
+          divs[inflight] = iter - 3;                                     // K:2287
+          if (dr_pipeline_submit(ctx, st, W, H, s.background, seed + frame_no * seed_stride, divs[inflight], &tickets[inflight]) != DR_OK) die("submit");
+          frame_no++; inflight++;
+          if (iter < total_iters && inflight < 2) continue;
+        }
+        if (dr_pipeline_wait(ctx, tickets[0], rgb.data()) != DR_OK) die("present");
+        divide_by = divs[0];
+        tickets[0] = tickets[1]; divs[0] = divs[1]; inflight--;
+        auto now = std::chrono::steady_clock::now();
+        long long us = std::chrono::duration_cast<std::chrono::microseconds>(now - t_prev).count();
+        t_prev = now;
+        if (!quiet) {
+          printf("\rTime = %lld[us]  %.2f FPS       %d samples             ", us, us > 0 ? 1e6 / (double)us : 0.0, divide_by * s.spp);   // K:2327
+          fflush(stdout);
+        }
+      }
+      break;
     } else {
       pack13(s, 1, s.spp, s.max_depth, st);
       n = total_iters - iter < group ? total_iters - iter : group;   // several frames per present

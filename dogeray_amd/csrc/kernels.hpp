@@ -41,6 +41,7 @@ int launch_persistent_kernel(hipStream_t stream, const RenderParams& P, const Pe
 struct PoolCfg {
   int num_cus;
   int shade_min;             // a wave shades once this many of its paths wait for it (or nothing else can be done)
+  int shape;                 // 0: 4 stack words in LDS, 15 waves per CU; 1: 3 words, 16 waves; 2: 8 words, 12 waves
   bool diag;                 // the build that counts batches, paths per batch and cycles per part of the loop (counters[16..])
 };
 constexpr int COUNTER_WORDS = 64;   // 64-bit words of a context's statistics buffer: [0, 8) ray counters, [8, 16) dr_stats.diag, [16, 48) kernel diagnostics

@@ -4,7 +4,8 @@
 // In the persistent kernel (kernels_render.hip) a path belongs to a LANE, and at any moment a wave's 64 lanes are spread over the
 // three kinds of work: measured on the bench scene a node step executes for 30 of its 64 lanes, a leaf step for 23, a shade phase
 // for 37 (lane use 0.36, profiles/r2_b).  Here a path belongs to a WAVE, which owns POOL_SLOTS = 128 of them -- twice its width --
-// with their whole state in LDS (ray, best hit, next record, stack, RNG, attenuation, pixel: 144 bytes each).  Per iteration the
+// with the state the walk needs in LDS (ray, 1/direction, best hit, next record, stack top and a few stack words: 80-84 bytes each) and
+// the rest (RNG, attenuation, pixel: 48 bytes, touched once per bounce) in a per-wave array in global memory.  Per iteration the
 // wave reads the stage tag of its 128 paths, picks ONE kind of step, compacts up to 64 paths that wait for that kind onto its lanes
 // (ranks from ballots, slot numbers through a 64-word exchange buffer), loads their state, does the step, stores the state and the
 // new tags.  With two paths per lane there are nearly always 64 that want a node step, or 64 that want a leaf step (a Monte-Carlo
@@ -17,13 +18,21 @@
 // ONE pool per workgroup with three shared queues; its batches were 63.9 lanes full and it was 2 x slower than the persistent
 // kernel (profiles/r3_a_pool_kernel_lds_queues.txt: 56 % of a wave's life went into claiming and pushing, about 15 dependent LDS
 // round trips per batch).  Here a batch costs three: tags, exchange buffer, state.
+// The second version kept ALL of a path's state in LDS (144 bytes): 8 waves per CU, and although its lanes were 68 % busy and it needed
+// 104 instead of 158 wave-level VALU instructions per ray, two waves per SIMD cannot hide a step's latency (VALU issuing 28 % of the
+// time; 0.99 ms/frame against 0.62, profiles/r3_b_pool_kernel_wave_private_8waves.txt).  Hence the split above: 15-16 waves per CU.
 //
 // New pixels come from the same per-XCD queues, tile order and frame batching as the persistent kernel's, counted in PIXELS: a shade
 // batch takes as many positions of its region's pixel sequence as it has paths without a pixel with one atomic add.  A path
 // that finds no pixel left dies; the wave leaves when all of its paths are dead.
 //
-// The stack of a path is POOL_LSTACK words in LDS; deeper words (the host bounds the depth at WIDE_STACK) go to a scratch array in
-// global memory -- rare -- so that 8 waves x 128 paths fit the CU's 160 KiB.
+// RESULT (profiles/r3_c_pool_kernel_more_waves.txt): batches 54-64 lanes full, 104 instead of 158 wave-level VALU instructions per ray, and
+// still 16 % SLOWER than the persistent kernel (0.717 against 0.616 ms/frame; C2 and C5 likewise): a batch's step is a chain of about 4 800
+// cycles for about 260 VALU instructions, so the 4 waves per SIMD that LDS allows keep the VALU 40 % busy, against 65-69 % for the six
+// register-resident waves of the persistent kernel.  Built only with -DDOGERAY_EXPERIMENTAL (tools/exp_variant.sh).
+//
+// The stack of a path is LSTACK (3-4) words in LDS besides the word in `top`; deeper words (the host bounds the depth at WIDE_STACK) go to
+// the wave's scratch in global memory.
 #include <hip/hip_runtime.h>
 
 #include "device_core.hpp"
@@ -32,34 +41,34 @@
 
 namespace dr {
 
-constexpr int POOL_WG_WAVES = 4;                // waves per workgroup (independent of each other; two workgroups per CU)
+#ifdef DOGERAY_EXPERIMENTAL      // MEASURED SLOWER than the persistent kernel on every scene (profiles/r3_c_pool_kernel_more_waves.txt): not in the product library
+
 constexpr int POOL_SLOTS = 128;                 // paths per wave: slot s belongs to lane s & 63
-constexpr int POOL_LSTACK = 8;                  // stack words per path kept in LDS
-constexpr int POOL_UNITS = 7;                   // 16-byte state units per path
+constexpr int POOL_UNITS = 4;                   // 16-byte state units per path in LDS
+constexpr int POOL_GUNITS = 3;                  // ... and in the wave's global array
 enum { PT_NODE = 0, PT_LEAF = 1, PT_SHADE = 2, PT_DEAD = 3 };
-// state units: U0 {o.xyz, best t} U1 {d.xyz, best slot} U2 {1/d.xyz, next record} U3 {stack top, stack pointer, steps, pixel code}
-//              U4 {rng v0..v3} U5 {rng v4, rng d, atten.xy} U6 {atten.z, (x + 1) << 16 | y, frame | bounce << 8, -}
+// LDS:    U0 {o.xyz, best t} U1 {d.xyz, best slot} U2 {1/d.xyz, next record} U3 {stack top, stack pointer, steps, pixel code}
+// global: G0 {rng v0..v3} G1 {rng v4, rng d, atten.xy} G2 {atten.z, (x + 1) << 16 | y, frame | bounce << 8, -}
 constexpr unsigned POOL_META_NEW = 0x80000000u; // the slot holds no path yet (or its path has ended): it needs a pixel
-constexpr int POOL_WAVE_LDS = POOL_UNITS * POOL_SLOTS * 16 + POOL_LSTACK * POOL_SLOTS * 4 + POOL_SLOTS * 4 + 64 * 4;      // bytes per wave
+constexpr int pool_wave_lds(int lstack) { return POOL_UNITS * POOL_SLOTS * 16 + lstack * POOL_SLOTS * 4 + POOL_SLOTS + 64 * 4; }      // bytes per wave
+constexpr int pool_wave_scratch(int lstack) { return (WIDE_STACK - lstack) * POOL_SLOTS + POOL_GUNITS * 4 * POOL_SLOTS; }               // 32-bit words per wave
 
-static_assert(2 * POOL_WG_WAVES * POOL_WAVE_LDS <= 160 * 1024, "two workgroups per CU");
-static_assert(POOL_LSTACK <= WIDE_STACK, "stack split");
-static_assert(POOL_SLOTS == 128, "two tag words per lane");
-
-// the per-path stack: words [0, POOL_LSTACK) in LDS, deeper ones in the wave's global scratch (past the L1)
+// the per-path stack: words [0, LSTACK) in LDS, deeper ones in the wave's global scratch
+template <int LSTACK>
 struct PoolStack {
   int* lds; unsigned* glob;   // both already offset by the slot
   __device__ __forceinline__ int ld(int k) const {
-    if (k < POOL_LSTACK) return lds[k * POOL_SLOTS];
-    return (int)__hip_atomic_load(glob + (k - POOL_LSTACK) * POOL_SLOTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k < LSTACK) return lds[k * POOL_SLOTS];
+    return (int)__hip_atomic_load(glob + (k - LSTACK) * POOL_SLOTS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __device__ __forceinline__ void st(int k, int v) const {
-    if (k < POOL_LSTACK) lds[k * POOL_SLOTS] = v;
-    else __hip_atomic_store(glob + (k - POOL_LSTACK) * POOL_SLOTS, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (k < LSTACK) lds[k * POOL_SLOTS] = v;
+    else __hip_atomic_store(glob + (k - LSTACK) * POOL_SLOTS, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
 
 // wide_pop (device_core.hpp) on a PoolStack
+template <class PoolStack>
 __device__ __forceinline__ void pool_pop(int& node, unsigned& top, int& sp, const PoolStack& stk) {
   if (top == 0u) {
     if (sp == 0) { node = -1; return; }
@@ -77,27 +86,29 @@ __device__ __forceinline__ unsigned pool_lane_rank(unsigned long long m) {
 }
 __device__ __forceinline__ int pool_next_tag(int node) { return node < 0 ? PT_SHADE : ((node & 1) ? PT_LEAF : PT_NODE); }
 
-template <bool DIAG>
-__global__ __launch_bounds__(POOL_WG_WAVES * 64, 2) void render_pool_kernel(RenderParams P, unsigned* __restrict__ tile_counter, const int* __restrict__ tile_order,
-                                                                            const int* __restrict__ region_start, unsigned* __restrict__ pixel_cost,
-                                                                            unsigned* __restrict__ scratch, int shade_min) {
-  __shared__ __attribute__((aligned(16))) float4 lds_units[POOL_WG_WAVES * POOL_UNITS * POOL_SLOTS];
-  __shared__ int lds_stack[POOL_WG_WAVES * POOL_LSTACK * POOL_SLOTS];
-  __shared__ int lds_tags[POOL_WG_WAVES * POOL_SLOTS];
-  __shared__ int lds_xch[POOL_WG_WAVES * 64];
+// LSTACK stack words per path in LDS, WG_WAVES waves per workgroup (independent of each other), WPS waves per SIMD the registers allow
+template <bool DIAG, int LSTACK, int WG_WAVES, int WPS>
+__global__ __launch_bounds__(WG_WAVES * 64, WPS) void render_pool_kernel(RenderParams P, unsigned* __restrict__ tile_counter, const int* __restrict__ tile_order,
+                                                                         const int* __restrict__ region_start, unsigned* __restrict__ pixel_cost,
+                                                                         unsigned* __restrict__ scratch, int shade_min) {
+  __shared__ __attribute__((aligned(16))) float4 lds_units[WG_WAVES * POOL_UNITS * POOL_SLOTS];
+  __shared__ int lds_stack[WG_WAVES * LSTACK * POOL_SLOTS];
+  __shared__ unsigned char lds_tags[WG_WAVES * POOL_SLOTS];
+  __shared__ int lds_xch[WG_WAVES * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float4* const units = lds_units + wave * (POOL_UNITS * POOL_SLOTS);      // unit u of slot s at units[u * POOL_SLOTS + s]
-  int* const stackw = lds_stack + wave * (POOL_LSTACK * POOL_SLOTS);       // word k of slot s at stackw[k * POOL_SLOTS + s]
-  int* const tags = lds_tags + wave * POOL_SLOTS;
+  int* const stackw = lds_stack + wave * (LSTACK * POOL_SLOTS);            // word k of slot s at stackw[k * POOL_SLOTS + s]
+  unsigned char* const tags = lds_tags + wave * POOL_SLOTS;
   int* const xch = lds_xch + wave * 64;
-  unsigned* const my_scratch = scratch + ((size_t)blockIdx.x * POOL_WG_WAVES + (size_t)wave) * (size_t)((WIDE_STACK - POOL_LSTACK) * POOL_SLOTS);
+  unsigned* const my_scratch = scratch + ((size_t)blockIdx.x * WG_WAVES + (size_t)wave) * (size_t)pool_wave_scratch(LSTACK);
+  float4* const gunits = reinterpret_cast<float4*>(my_scratch + (WIDE_STACK - LSTACK) * POOL_SLOTS);      // unit k of slot s at gunits[s * POOL_GUNITS + k]
   const WalkRsrc walk = wide_rsrc(P);
   const unsigned long long t_begin = __builtin_readcyclecounter(), r_begin = __builtin_amdgcn_s_memrealtime();
 
   // ---- every slot starts without a path and waits for a pixel
   tags[lane] = PT_SHADE; tags[lane + 64] = PT_SHADE;
-  units[6 * POOL_SLOTS + lane] = make_float4(0.0f, 0.0f, __uint_as_float(POOL_META_NEW), 0.0f);
-  units[6 * POOL_SLOTS + lane + 64] = make_float4(0.0f, 0.0f, __uint_as_float(POOL_META_NEW), 0.0f);
+  gunits[lane * POOL_GUNITS + 2] = make_float4(0.0f, 0.0f, __uint_as_float(POOL_META_NEW), 0.0f);
+  gunits[(lane + 64) * POOL_GUNITS + 2] = make_float4(0.0f, 0.0f, __uint_as_float(POOL_META_NEW), 0.0f);
 
   // work queues as in the persistent kernel (tile order of the cost feedback, frames of a batch interleaved, one queue per region =
   // XCD; a wave helps the next region once its own is empty), but counted in pixels
@@ -139,7 +150,7 @@ __global__ __launch_bounds__(POOL_WG_WAVES * 64, 2) void render_pool_kernel(Rend
     float* const u1 = reinterpret_cast<float*>(units + 1 * POOL_SLOTS + sidx);
     float* const u2 = reinterpret_cast<float*>(units + 2 * POOL_SLOTS + sidx);
     float* const u3 = reinterpret_cast<float*>(units + 3 * POOL_SLOTS + sidx);
-    PoolStack stk; stk.lds = stackw + sidx; stk.glob = my_scratch + sidx;
+    PoolStack<LSTACK> stk; stk.lds = stackw + sidx; stk.glob = my_scratch + sidx;
 
     unsigned long long d_ta = 0, d_tb = 0;
     if (stage == PT_NODE) {
@@ -201,22 +212,19 @@ __global__ __launch_bounds__(POOL_WG_WAVES * 64, 2) void render_pool_kernel(Rend
     } else {
       // ================= shade: one bounce of raycolor (K:807-976) for every path of the batch whose walk has ended; paths that end
       // store their pixel (K:1081-1085) and the slot takes the next pixel (camera ray K:1065-1073)
-      float* const u4 = reinterpret_cast<float*>(units + 4 * POOL_SLOTS + sidx);
-      float* const u5 = reinterpret_cast<float*>(units + 5 * POOL_SLOTS + sidx);
-      float* const u6 = reinterpret_cast<float*>(units + 6 * POOL_SLOTS + sidx);
+      float4* const g = gunits + sidx * POOL_GUNITS;               // RNG, attenuation, pixel: this wave's array in global memory
       Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
       Xorwow rng; rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = rng.d = 0;
       int px = -1, py = 0, pcode = 0, frame = 0, bounce = 0;
       unsigned steps = 0;
       bool want_pixel = false, alive = false;
       if (slot >= 0) {
-        const float4 A6 = *reinterpret_cast<const float4*>(u6);
+        const float4 A4 = g[0], A5 = g[1], A6 = g[2];
         const unsigned meta = __float_as_uint(A6.z);
         if (meta & POOL_META_NEW) {
           want_pixel = true;
         } else {
           const float4 A0 = *reinterpret_cast<const float4*>(u0), A1 = *reinterpret_cast<const float4*>(u1), A3 = *reinterpret_cast<const float4*>(u3);
-          const float4 A4 = *reinterpret_cast<const float4*>(u4), A5 = *reinterpret_cast<const float4*>(u5);
           path.rayo = mk(A0.x, A0.y, A0.z); path.raydir = mk(A1.x, A1.y, A1.z); path.atten = mk(A5.z, A5.w, A6.x);
           const float best_t = A0.w; const int best_slot = __float_as_int(A1.w);
           rng.v0 = __float_as_uint(A4.x); rng.v1 = __float_as_uint(A4.y); rng.v2 = __float_as_uint(A4.z); rng.v3 = __float_as_uint(A4.w);
@@ -289,9 +297,9 @@ __global__ __launch_bounds__(POOL_WG_WAVES * 64, 2) void render_pool_kernel(Rend
         *reinterpret_cast<float4*>(u1) = make_float4(path.raydir.x, path.raydir.y, path.raydir.z, __int_as_float(-1));
         *reinterpret_cast<float4*>(u2) = make_float4(inv.x, inv.y, inv.z, __int_as_float(0));
         *reinterpret_cast<float4*>(u3) = make_float4(__uint_as_float(0u), __int_as_float(0), __uint_as_float(steps), __int_as_float(pcode));
-        *reinterpret_cast<float4*>(u4) = make_float4(__uint_as_float(rng.v0), __uint_as_float(rng.v1), __uint_as_float(rng.v2), __uint_as_float(rng.v3));
-        *reinterpret_cast<float4*>(u5) = make_float4(__uint_as_float(rng.v4), __uint_as_float(rng.d), path.atten.x, path.atten.y);
-        *reinterpret_cast<float4*>(u6) = make_float4(path.atten.z, __int_as_float(((px + 1) << 16) | py), __uint_as_float((unsigned)frame | ((unsigned)bounce << 8)), 0.0f);
+        g[0] = make_float4(__uint_as_float(rng.v0), __uint_as_float(rng.v1), __uint_as_float(rng.v2), __uint_as_float(rng.v3));
+        g[1] = make_float4(__uint_as_float(rng.v4), __uint_as_float(rng.d), path.atten.x, path.atten.y);
+        g[2] = make_float4(path.atten.z, __int_as_float(((px + 1) << 16) | py), __uint_as_float((unsigned)frame | ((unsigned)bounce << 8)), 0.0f);
         tags[slot] = PT_NODE;
       }
     }
@@ -319,21 +327,43 @@ bool pool_kernel_can_render(const RenderParams& P) {
   return P.wide != nullptr && P.max_depth > 0 && P.max_depth < (1 << 22) && P.spp_f > 0.0f && P.spp_f <= 1.0f && P.batch >= 1 && P.batch <= 256;
 }
 
-// two workgroups of four waves on every CU
-static int pool_blocks(int num_cus) { return num_cus * 2; }
-size_t pool_scratch_words(int num_cus) { return (size_t)pool_blocks(num_cus) * POOL_WG_WAVES * (size_t)((WIDE_STACK - POOL_LSTACK) * POOL_SLOTS); }
+// the shapes built: stack words in LDS / waves per workgroup / workgroups per CU (the LDS of a CU: 160 KiB) / waves per SIMD
+struct PoolShape { int lstack, wg_waves, wgs_per_cu; };
+static const PoolShape pool_shapes[] = {{4, 5, 3}, {3, 4, 4}, {8, 4, 3}};
+static_assert(3 * 5 * pool_wave_lds(4) <= 160 * 1024 && 4 * 4 * pool_wave_lds(3) <= 160 * 1024 && 3 * 4 * pool_wave_lds(8) <= 160 * 1024, "LDS of a CU");
+static inline const PoolShape& pool_shape(int k) { return pool_shapes[k < 0 || k > 2 ? 0 : k]; }
+
+size_t pool_scratch_words(int num_cus) {      // enough for every shape
+  size_t most = 0;
+  for (const PoolShape& sh : pool_shapes) {
+    const size_t w = (size_t)num_cus * sh.wgs_per_cu * sh.wg_waves * (size_t)pool_wave_scratch(sh.lstack);
+    if (w > most) most = w;
+  }
+  return most;
+}
 
 void launch_pool_kernel(hipStream_t stream, const RenderParams& P, const PoolCfg& cfg, unsigned* tile_counter, const int* order, const int* region_start,
                         unsigned* pixel_cost, unsigned* scratch) {
+  const PoolShape& sh = pool_shape(cfg.shape);
   const long long work = (long long)P.ncols * P.gy * P.batch;      // chunks of 64 pixels
-  const long long per_block = POOL_WG_WAVES * (POOL_SLOTS / 64);
-  long long blocks = pool_blocks(cfg.num_cus);
+  const long long per_block = sh.wg_waves * (POOL_SLOTS / 64);
+  long long blocks = (long long)cfg.num_cus * sh.wgs_per_cu;
   if (blocks * per_block > work) blocks = (work + per_block - 1) / per_block;
   if (blocks < 1) blocks = 1;
-  if (cfg.diag) hipLaunchKernelGGL((render_pool_kernel<true>), dim3((unsigned)blocks), dim3(POOL_WG_WAVES * 64), 0, stream, P, tile_counter, order, region_start, pixel_cost,
-                                   scratch, cfg.shade_min);
-  else hipLaunchKernelGGL((render_pool_kernel<false>), dim3((unsigned)blocks), dim3(POOL_WG_WAVES * 64), 0, stream, P, tile_counter, order, region_start, pixel_cost,
-                          scratch, cfg.shade_min);
+#define DR_POOL_LAUNCH(DIAG, LSTACK, WGW, WPS)                                                                                                   \
+  hipLaunchKernelGGL((render_pool_kernel<DIAG, LSTACK, WGW, WPS>), dim3((unsigned)blocks), dim3(WGW * 64), 0, stream, P, tile_counter, order, region_start, \
+                     pixel_cost, scratch, cfg.shade_min)
+  if (cfg.shape == 1) { if (cfg.diag) DR_POOL_LAUNCH(true, 3, 4, 4); else DR_POOL_LAUNCH(false, 3, 4, 4); }
+  else if (cfg.shape == 2) { if (cfg.diag) DR_POOL_LAUNCH(true, 8, 4, 3); else DR_POOL_LAUNCH(false, 8, 4, 3); }
+  else { if (cfg.diag) DR_POOL_LAUNCH(true, 4, 5, 4); else DR_POOL_LAUNCH(false, 4, 5, 4); }
+#undef DR_POOL_LAUNCH
 }
 
+#else   // product build
+
+bool pool_kernel_can_render(const RenderParams&) { return false; }
+size_t pool_scratch_words(int) { return 0; }
+void launch_pool_kernel(hipStream_t, const RenderParams&, const PoolCfg&, unsigned*, const int*, const int*, unsigned*, unsigned*) {}
+
+#endif
 }  // namespace dr

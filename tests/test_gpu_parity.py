@@ -252,6 +252,52 @@ def test_progressive_accumulation(dr, orc, ctx, tmp_path):
         assert np.array_equal(img, want.transpose(1, 0, 2))
 
 
+def test_pipelined_present_loop(dr, orc, ctx, synth, tmp_path):
+    """dr_pipeline_submit / dr_pipeline_wait (frame k + 1 starts while frame k drains; per-frame buffers added in ticket order): every
+    displayed image is exactly clamp(sum of the oracle's frames so far / count) (K:2213-2218, K:2287), the accumulator ends as their sum,
+    and calls of the ordinary API afterwards see all of it.  Long enough for the tile order to be refreshed inside the pipeline."""
+    path = with_settings(os.path.join(SCENES, "cube.rts"), str(tmp_path / "cube256.rts"), CUBE_SETTINGS)
+    ps, os_ = _load_both(dr, orc, path)
+    ctx.upload(ps)
+    s = ps.settings()
+    pr = dr.ProgressiveRenderer(ctx, s, seed_base=1, seed_stride=1000003)
+    outr = None
+    for k in range(4):
+        pr.step()
+        st = dr.pack_settings13(s, (8, 4, 2, 1)[k], spp=(None if k == 0 else 1), depth=(None if k == 0 else 2))
+        outr, _ = os_.render(st, 256, 256, s.background, 1 + 1000003 * k, nthreads=4)
+    n = 21
+    sums = []
+    for k in range(4, 4 + n):
+        f, _ = os_.render(dr.pack_settings13(s, 1), 256, 256, s.background, 1 + 1000003 * k, nthreads=4)
+        outr = outr + f
+        sums.append(outr.copy())
+    shown = []
+    pr.run_pipelined(n, on_image=lambda it, dv, img: shown.append((it, dv, img.copy())))
+    assert [it for it, _, _ in shown] == list(range(5, 5 + n))
+    for j, (it, dv, img) in enumerate(shown):
+        assert dv == it - 3
+        quot = (np.abs(sums[j]) // dv) * np.sign(sums[j])
+        want = np.clip(quot, 0, 255).astype(np.uint8).transpose(1, 0, 2)
+        assert np.array_equal(img, want), "image shown after iteration %d" % it
+    assert np.array_equal(ctx.accum_read(), sums[-1])
+    # and on a larger frame with textures, without presents, against the batched accumulation
+    ps2 = dr.Scene.load(os.path.join(synth["dir"], "matball.rts"), synth["tex"])
+    ps2.build_bvh()
+    ctx.upload(ps2)
+    s2 = ps2.settings()
+    st2 = dr.pack_settings13(s2, 1)
+    ctx.accum_reset(256, 256)
+    ctx.render_accumulate(st2, 256, 256, s2.background, 9, 1000003, 13)
+    want = ctx.accum_read()
+    ctx.accum_reset(256, 256)
+    ctx.render_accumulate_pipelined(st2, 256, 256, s2.background, 9, 1000003, 13)
+    assert np.array_equal(ctx.accum_read(), want)
+    ctx.render_accumulate_pipelined(st2, 256, 256, s2.background, 9, 1000003, 13)      # on top of it, then an ordinary call behind the pipeline
+    ctx.render_accumulate(st2, 256, 256, s2.background, 9, 1000003, 13)
+    assert np.array_equal(ctx.accum_read().astype(np.int64), 3 * want.astype(np.int64))
+
+
 def test_moving_camera_keeps_the_previous_views_tile_order(dr, orc, ctx, synth):
     """An interactive viewer changes the camera between frames (K:2341-2500: every frame is a new view).  The persistent kernel then starts
     from the previous view's tile order (same tile grid: any order is a valid order) instead of none -- frames identical to the oracle's,
@@ -645,7 +691,7 @@ def test_waves_with_roles_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tm
 
 
 def test_pool_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
-    """render_pool_kernel (kernels_pool.hip; the default for long launches, forced here with option "pool" = 2): every wave owns 128
+    """render_pool_kernel (kernels_pool.hip, experimental builds; forced for every launch with option "pool" = 2): every wave owns 128
     paths in LDS and runs one kind of step at a time for up to 64 of them.  Every material, textures, spheres, margins of the preview
     divisor, frames that are not multiples of 8, fuzzed scenes with coincident triangles (deep trees: stack words in the global scratch),
     shade thresholds from 1 to 128 -- frames identical to the oracle's."""
@@ -658,16 +704,20 @@ def test_pool_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
              (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192, 1), (os.path.join(synth["dir"], "hf_small.rts"), "", 320, 192, 1),
              (os.path.join(synth["dir"], "bunny_small.rts"), "", 203, 117, 1), (os.path.join(synth["dir"], "city_small.rts"), "", 640, 360, 1)]
     cases += [(random_scene(rng, int(rng.integers(2, 900)), str(tmp_path / ("pool%d.rts" % k)), W=96, H=64, textures=names), synth["tex"], 96, 64, 1) for k in range(8)]
+    if not ctx.get_option("experimental"):
+        pytest.skip("render_pool_kernel is only in -DDOGERAY_EXPERIMENTAL builds of the library (tools/exp_variant.sh): measured slower")
     ctx.set_option("pool", 2)
     try:
-        for fill in (48, 1, 128):
+        for fill, shape in ((48, 0), (1, 1), (128, 2), (48, 1)):      # shape: stack words kept in LDS / waves per CU (4 / 15, 3 / 16, 8 / 12)
             ctx.set_option("pool_shade_min", fill)
+            ctx.set_option("pool_shape", shape)
             for path, tex, W, H, div in cases:
                 g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, div, 777, spp=1, mode=2, kernel=1)      # (more samples per pixel go to the persistent kernel)
-                _assert_frames(g, r, "%s pool kernel, shade_min %d" % (os.path.basename(path), fill))
+                _assert_frames(g, r, "%s pool kernel, shade_min %d, shape %d" % (os.path.basename(path), fill, shape))
     finally:
-        ctx.set_option("pool", 1)
+        ctx.set_option("pool", 0)
         ctx.set_option("pool_shade_min", 48)
+        ctx.set_option("pool_shape", 0)
 
 
 def test_pool_kernel_batched_accumulation(dr, orc, ctx, synth):
@@ -683,6 +733,8 @@ def test_pool_kernel_batched_accumulation(dr, orc, ctx, synth):
     for k in range(n):
         f, _ = os_.render(st, W, H, s.background, 5 + 1000003 * k, nthreads=4)
         total += f
+    if not ctx.get_option("experimental"):
+        pytest.skip("render_pool_kernel is only in -DDOGERAY_EXPERIMENTAL builds of the library")
     ctx.set_option("pool", 2)
     try:
         for regions in (1, 0):
@@ -693,6 +745,6 @@ def test_pool_kernel_batched_accumulation(dr, orc, ctx, synth):
                 ctx.render_accumulate(st, W, H, s.background, 5, 1000003, n)
                 assert np.array_equal(ctx.accum_read().astype(np.int64), total), (regions, rep)
     finally:
-        ctx.set_option("pool", 1)
+        ctx.set_option("pool", 0)
         ctx.set_option("xcd_regions", 1)
         ctx.set_option("short_one_queue", 1)
