@@ -25,6 +25,16 @@
 
 #include "device_layout.h"
 
+// tools/instr_budget.py builds the render kernels with -DDR_ISA_MARKS=1 -save-temps and counts the instructions between these comments
+#ifndef DR_ISA_MARKS
+#define DR_ISA_MARKS 0
+#endif
+#if DR_ISA_MARKS
+#define DR_MARK(s) asm volatile("; DRMARK " s)
+#else
+#define DR_MARK(s) do {} while (0)
+#endif
+
 namespace dr {
 
 struct V3 { float x, y, z; };
@@ -499,6 +509,7 @@ __device__ __forceinline__ WideRec wide_fetch(WalkRsrc wide, int node) {
 
 template <bool COUNT>
 __device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv, const WideRay& wr, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
+  DR_MARK("node_begin");
   if (COUNT) c.V++;
 #if DR_PAD_VALU
   _Pragma("unroll") for (int k = 0; k < DR_PAD_VALU; k++) asm volatile("v_or_b32 %0, 0, %0" : "+v"(tr.best_slot));
@@ -520,11 +531,13 @@ __device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv
   } else {
     wide_pop(tr, ws, stack);
   }
+  DR_MARK("node_end");
 }
 
 template <bool COUNT>
 __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, V3 inv, Trav& tr, WideStack& ws, const int* __restrict__ stack, Ctr& c) {
   auto f = [](unsigned v) { return __uint_as_float(v); };
+  DR_MARK("leaf_begin");
   if (COUNT) c.V++;
   float mn[3] = {f(r.A.x), f(r.A.y), f(r.A.z)}, mx[3] = {f(r.B.x), f(r.B.y), f(r.B.z)};
   float dist;
@@ -536,6 +549,7 @@ __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, 
     if (t > 0.0f && (t < tr.best_t || (t == tr.best_t && (unsigned)slot < (unsigned)tr.best_slot))) { tr.best_t = t; tr.best_slot = slot; }
   }
   wide_pop(tr, ws, stack);
+  DR_MARK("leaf_end");
 }
 
 template <bool COUNT>

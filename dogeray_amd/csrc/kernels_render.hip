@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   unsigned long long d_phases = 0, d_given = 0, d_walking = 0, d_phase_ticks = 0;      // -DDR_WAVE_LOG_DETAIL builds: phases, hand-overs, walking lanes summed, ticks inside phases, all after the queue ran empty
   ParkedLeaf pk; pk.v0x = 0; pk.C = pk.D = u32x4{0, 0, 0, 0}; pk.info = 0; pk.parked = false;   // PARK_MIN > 0 only
   for (;;) {
+    DR_MARK("loop_top");
     const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;
     if (WAVE_LOG && r_empty != 0ull) n_after++;
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
     // (a holding wave -- long pixels, helpers walking for them -- shades as soon as a ray is finished: its pixels' latency is the point)
     if ((__popcll(walking) < TRAV_MIN || (WIDE && COOP && held)) && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers) || tr.node == -2) != 0ull)) {
       unsigned long long t0 = 0;
+      DR_MARK("phase_begin");
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
       unsigned long long d_t0 = 0;
       if (DR_WAVE_LOG_DETAIL && r_empty != 0ull) { d_phases++; d_t0 = __builtin_amdgcn_s_memrealtime(); }
@@ -370,6 +372,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
       if (DR_WAVE_LOG_DETAIL && d_t0 != 0ull) d_phase_ticks += __builtin_amdgcn_s_memrealtime() - d_t0;
+      DR_MARK("phase_end");
       if (__ballot(tr.node != -3) == 0ull) break;
     }
     if (WIDE && COOP && !COUNT && P.coop_steps > 0 && (cur_tile >= ntiles || held)) {

@@ -20,8 +20,11 @@
 // child-0-first order.  Scenes this cannot represent (non-finite leaf boxes, more than 2^24 records, depth
 // beyond the kernel's stack) make build_wide() return false and the context falls back to the threaded walk.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <new>
+#include <system_error>
 #include <thread>
 
 #include "linearise.hpp"
@@ -64,6 +67,9 @@ struct SahBuilder {
     struct Item { int id, first, count, levels, depth; };
     std::vector<Item> stack;
     std::vector<std::thread> spawned;
+    // whatever happens below (an allocation that throws, a thread that cannot be created), the threads already running are joined
+    // before this frame goes away: a joinable std::thread destroyed during unwinding would end the process
+    struct Joiner { std::vector<std::thread>& v; ~Joiner() { for (std::thread& t : v) if (t.joinable()) t.join(); } } joiner{spawned};
     stack.push_back({id, first, count, levels, depth});
     while (!stack.empty()) {
       const Item it = stack.back();
@@ -144,7 +150,12 @@ struct SahBuilder {
       if (nl > 1) {
         if (fork) {
           const int f = it.first, lv = it.levels - 1, d = it.depth + 1;
-          spawned.emplace_back([this, lid, f, nl, lv, d]() { subtree(lid, f, nl, lv, d); });
+          try {
+            // (an exception must not leave a thread function: it is noted, and build() rethrows after everybody has been joined)
+            spawned.emplace_back([this, lid, f, nl, lv, d]() { try { subtree(lid, f, nl, lv, d); } catch (...) { failed.store(true); } });
+          } catch (const std::system_error&) {
+            stack.push_back({lid, f, nl, lv, d});                          // no more threads to be had: this subtree on our own stack
+          }
         } else {
           stack.push_back({lid, it.first, nl, it.levels - 1, it.depth + 1});
         }
@@ -152,6 +163,7 @@ struct SahBuilder {
     }
     for (std::thread& t : spawned) t.join();
   }
+  std::atomic<bool> failed{false};
 };
 
 struct WNode {
@@ -308,6 +320,7 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
     while ((1 << sb.par_depth) < nthreads && sb.par_depth < 6) sb.par_depth++;
     if (nthreads <= 1) sb.par_depth = 0;
     sb.subtree(0, 0, N, MAX_BINARY_DEPTH, 0);
+    if (sb.failed.load()) throw std::bad_alloc();      // a worker ran out of memory: dr_context_upload_scene reports it
     bn.swap(sb.nodes);
   }
 

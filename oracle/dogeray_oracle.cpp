@@ -362,6 +362,12 @@ bool read_rts(Scene& s, const std::string& file) {
 }
 
 // ------------------------------------------------------------------ BVH build (K:335-406,1534-1909)
+// (the -DORACLE_FMA_KERNEL variant, liboracle_fma.so, contracts a*b+c into fused multiply-adds in the DEVICE functions only -- what nvcc's
+// default -fmad=true does to kernel.cu's __device__ code; the BVH build is host code of the reference and stays uncontracted)
+#ifdef ORACLE_FMA_KERNEL
+#pragma GCC push_options
+#pragma GCC optimize("fp-contract=off")
+#endif
 struct Builder {
   Scene& s;
   explicit Builder(Scene& sc) : s(sc) {}
@@ -487,6 +493,9 @@ struct Builder {
     return true;
   }
 };
+#ifdef ORACLE_FMA_KERNEL
+#pragma GCC pop_options
+#endif
 
 // ------------------------------------------------------------------ RNG (cuRAND XORWOW)
 struct Xorwow {

@@ -748,3 +748,14 @@ def test_pool_kernel_batched_accumulation(dr, orc, ctx, synth):
         ctx.set_option("pool", 0)
         ctx.set_option("xcd_regions", 1)
         ctx.set_option("short_one_queue", 1)
+
+
+def test_fuzz_campaign_slice(dr, orc, ctx, synth, tmp_path):
+    """A 200-scene slice of tools/fuzz_campaign.py inside the suite: random scenes x random settings of the work-sharing drain, split
+    tiles, occupancy, batching, tile-order refresh and the pipeline (streams, lean build) x frame sizes that are not multiples of 8;
+    single frames three times, batched and pipelined accumulation -- everything equal to the oracle's frames."""
+    from fuzz_driver import run_campaign
+    names = ["synth_albedo.ppm", "synth_rough.ppm", "synth_env.ppm", "a.ppm"]
+    n, frames, bad = run_campaign(dr, orc, ctx, 200, 20261004, str(tmp_path), synth["tex"], names)
+    print("fuzz slice: %d scenes, %d frames, %d mismatching" % (n, frames, len(bad)))
+    assert not bad, bad[:5]
