@@ -842,7 +842,10 @@ int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, 
               c->order_age % (4 * c->feedback_every) == 0;
   }
   if (c->pipe_barrier_set) HIP_TRY(hipStreamWaitEvent(rs, c->pipe_barrier, 0));
-  if (refresh || c->tile_cursor + MAX_REGIONS > TILE_COUNTERS)
+  // the tile counters are cleared (on this launch's stream) when the cursor wraps: like a refresh, that launch runs alone -- nobody may
+  // still count on the old values, and nobody may start on the new ones before they are cleared
+  const bool alone = refresh || c->tile_cursor + MAX_REGIONS > TILE_COUNTERS;
+  if (alone)
     for (int q = 0; q < dr_context::PIPE_STREAMS; q++) if (q != si && c->pipe_last_set[q]) HIP_TRY(hipStreamWaitEvent(rs, c->pipe_last[q], 0));
   if (tiles > 0) {
     hipStream_t saved = c->stream;
@@ -853,7 +856,7 @@ int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, 
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(c->pipe_last[si], rs)); c->pipe_last_set[si] = true;
-  if (refresh) { HIP_TRY(hipEventRecord(c->pipe_barrier, rs)); c->pipe_barrier_set = true; }
+  if (alone) { HIP_TRY(hipEventRecord(c->pipe_barrier, rs)); c->pipe_barrier_set = true; }
   HIP_TRY(hipEventRecord(c->pipe_rendered[slot], rs));
   // fold into the accumulator, in ticket order (K:2213-2218), and make the image of exactly the frames so far (K:2287)
   HIP_TRY(hipStreamWaitEvent(c->acc_stream, c->pipe_rendered[slot], 0));

@@ -267,13 +267,15 @@ __global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, con
 
 // acc += frame, 16 bytes per lane (pipelined single frames: every frame renders into a buffer of its own and is folded into
 // the accumulator in frame order, K:2213-2218)
-__global__ __launch_bounds__(256) void frame_add_kernel(int4* __restrict__ acc, const int4* __restrict__ frame, size_t n4) {
+__global__ __launch_bounds__(256) void frame_add_kernel(int4* __restrict__ acc, const int4* __restrict__ frame, size_t n4, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     int4 a = acc[i];
     const int4 f = frame[i];
     a.x += f.x; a.y += f.y; a.z += f.z; a.w += f.w;
     acc[i] = a;
   }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3))       // W * H * 3 need not be a multiple of 4
+    reinterpret_cast<int*>(acc)[n4 * 4 + threadIdx.x] += reinterpret_cast<const int*>(frame)[n4 * 4 + threadIdx.x];
 }
 
 // ------------------------------------------------------------------ launchers
@@ -286,10 +288,10 @@ void launch_present(hipStream_t stream, const int32_t* acc, uint8_t* rgb, int W,
   const int n = W * H;
   hipLaunchKernelGGL(present_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, acc, rgb, W, H, div);
 }
-void launch_frame_add(hipStream_t stream, int32_t* acc, const int32_t* frame, size_t n) {      // n int32, a multiple of 4 (W * H * 3 with 8 | W)
+void launch_frame_add(hipStream_t stream, int32_t* acc, const int32_t* frame, size_t n) {      // n int32
   const size_t n4 = n / 4;
-  size_t blocks = (n4 + 255) / 256; if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(frame_add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<int4*>(acc), reinterpret_cast<const int4*>(frame), n4);
+  size_t blocks = (n4 + 255) / 256; if (blocks > 2048) blocks = 2048; if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(frame_add_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, reinterpret_cast<int4*>(acc), reinterpret_cast<const int4*>(frame), n4, n);
 }
 void launch_stripe_copy(hipStream_t stream, int32_t* dst, const int32_t* src, int ncols, int run4, long long dst_first4, long long dst_stride4,
                         long long src_first4, long long src_stride4) {

@@ -33,22 +33,28 @@ def run_campaign(dr, orc, ctx, n_scenes, seed, workdir, texdir, texture_names, s
             fseed = 100 + k
             ref, _ = osc.render(st, W, H, s.background, fseed, nthreads=8)
             ok = True
+            what = []
             for rep in range(3):
                 g = ctx.render_frame(st, W, H, s.background, fseed); frames += 1
-                ok &= bool(np.array_equal(g, ref))
+                if not np.array_equal(g, ref): what.append("single frame, launch %d: %d pixels" % (rep, int(np.any(g != ref, axis=2).sum())))
             n = int(rng.integers(2, 6))
             total = ref.astype(np.int64).copy()
             for f in range(1, n):
                 total += osc.render(st, W, H, s.background, fseed + 1000003 * f, nthreads=8)[0]
             ctx.accum_reset(W, H)
             ctx.render_accumulate(st, W, H, s.background, fseed, 1000003, n); frames += n
-            ok &= bool(np.array_equal(ctx.accum_read().astype(np.int64), total))
+            got = ctx.accum_read().astype(np.int64)
+            if not np.array_equal(got, total): what.append("batched accumulation of %d frames: %d pixels" % (n, int(np.any(got != total, axis=2).sum())))
             ctx.accum_reset(W, H)
             ctx.render_accumulate_pipelined(st, W, H, s.background, fseed, 1000003, n); frames += n
-            ok &= bool(np.array_equal(ctx.accum_read().astype(np.int64), total))
+            got = ctx.accum_read().astype(np.int64)
+            if not np.array_equal(got, total):
+                where = np.argwhere(np.any(got != total, axis=2))
+                what.append("pipelined accumulation of %d frames: %d pixels, first (x, y) %r, got %r want %r" % (n, len(where), where[:4].tolist(), got[tuple(where[0])].tolist(), total[tuple(where[0])].tolist()))
+            ok = not what
             os.remove(path)
             if not ok:
-                bad.append("scene %d (%d objects, %dx%d) options %r" % (k, nobj, W, H, opts))
+                bad.append("scene %d (%d objects, %dx%d) options %r: %s" % (k, nobj, W, H, opts, "; ".join(what)))
                 log("MISMATCH " + bad[-1])
             elif k % 25 == 0:
                 log("scene %d ok (%d objects, %dx%d, %r)" % (k, nobj, W, H, opts))
