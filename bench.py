@@ -620,6 +620,34 @@ def main():
                           "(+%.1f s oracle parse+BVH, not timed)" % (ncpu, args.cpu_col_mod, nfr, W, H, cpu_rays, dt, t_setup),
                 "pixels_identical_to_gpu_on_sample": same,
             }
+            # north_star's named baseline: the build's OWN kernel source compiled for the host (tools/host_kernel.cpp = device_core.hpp with
+            # -DDR_HOST_BUILD, wide walk, std::threads over block columns), same sample of the same frames
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import host_kernel as hk
+                hsc = hk.Scene(scene_path, texdir or "")
+                hk_rays, hdt, hfr, himg = 0, 0.0, 0, None
+                while hfr < args.steps and hdt < 2.0:
+                    t0 = time.perf_counter()
+                    fr, c = hsc.render(st, W, H, s.background, seed_base + (args.warmup + hfr) * seed_stride, traversal=2, nthreads=ncpu,
+                                       col_mod=args.cpu_col_mod, col_rem=0)
+                    hdt += time.perf_counter() - t0
+                    hk_rays += c["rays"]
+                    if himg is None:
+                        himg = fr
+                    hfr += 1
+                t0 = time.perf_counter()
+                _, h1 = hsc.render(st, W, H, s.background, seed_base + args.warmup * seed_stride, traversal=2, nthreads=1, col_mod=2, col_rem=0)
+                hdt1 = time.perf_counter() - t0
+                result["cpu_baseline"]["same_source"] = {
+                    "value": hk_rays / hdt / 1e6, "unit": "Mrays/s", "cores": ncpu, "kind": "same-source",
+                    "single_thread": {"value": h1["rays"] / hdt1 / 1e6, "unit": "Mrays/s", "cores": 1},
+                    "sample": "tools/host_kernel.cpp (the library's device_core.hpp compiled for the host, wide walk), %d std::threads, the same block columns of "
+                              "the first %d frames: %d rays in %.2f s" % (ncpu, hfr, hk_rays, hdt),
+                    "pixels_identical_to_gpu_on_sample": float(np.all(gpu[cols] == himg[cols], axis=2).mean()),
+                }
+            except Exception as e:
+                result["cpu_baseline"]["same_source"] = {"value": None, "kind": "same-source", "sample": "failed: %r" % (e,)}
         except Exception as e:   # the baseline is a reported extra; never lose the GPU line over it
             result["cpu_baseline"] = {"value": None, "unit": "Mrays/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 

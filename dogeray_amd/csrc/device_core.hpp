@@ -7,7 +7,11 @@
 // precomputation) and how lanes are scheduled.  Build with -ffp-contract=off: no FMA
 // contraction, IEEE division and square root.
 #pragma once
+#ifdef DR_HOST_BUILD            // tools/host_kernel.cpp: the same arithmetic compiled for the host (a CPU baseline and a CPU-side check; never in the product library)
+#include "host_stubs.hpp"
+#else
 #include <hip/hip_runtime.h>
+#endif
 // Sensitivity experiments (tools/exp_variant.sh): useless extra work in the wide walk's node step.  All 0 in the product.
 #ifndef DR_WAVE_LOG_DETAIL
 #define DR_WAVE_LOG_DETAIL 0  // experiment builds: the wave log (option wave_log) also counts phases, hand-overs and walking lanes of the drain
@@ -222,6 +226,20 @@ __device__ __forceinline__ void trav_begin(Trav& tr) { tr.node = 0; tr.best_t = 
 // came in as dwordx2 + unaligned dwordx4 + dwordx3), so a node costs exactly two 16-byte requests
 // and a leaf four, all issued before the first wait.
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#ifdef DR_HOST_BUILD
+struct WalkRsrc { const unsigned char* base; unsigned bytes; };      // a buffer descriptor's base and range; loads past the range return 0, as the hardware's do
+__device__ __forceinline__ WalkRsrc walk_rsrc(const RenderParams& P) { WalkRsrc r; r.base = (const unsigned char*)P.walk; r.bytes = P.walk_bytes; return r; }
+__device__ __forceinline__ WalkRsrc wide_rsrc(const RenderParams& P) { WalkRsrc r; r.base = (const unsigned char*)P.wide; r.bytes = P.wide_bytes; return r; }
+__device__ __forceinline__ u32x4 host_buffer_load_b128(WalkRsrc r, unsigned byte_off) {
+  u32x4 v = {0u, 0u, 0u, 0u};
+  if ((unsigned long long)byte_off + 16ull <= (unsigned long long)r.bytes) memcpy(&v, r.base + byte_off, 16);
+  return v;
+}
+__device__ __forceinline__ float4 ld_unit(WalkRsrc r, unsigned byte_off) {
+  u32x4 v = host_buffer_load_b128(r, byte_off);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+#else
 typedef __amdgpu_buffer_rsrc_t WalkRsrc;
 __device__ __forceinline__ WalkRsrc walk_rsrc(const RenderParams& P) {
   return __builtin_amdgcn_make_buffer_rsrc((void*)P.walk, 0, (int)P.walk_bytes, 0x00020000);
@@ -233,6 +251,7 @@ __device__ __forceinline__ float4 ld_unit(WalkRsrc r, unsigned byte_off) {
   u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+#endif
 
 template <bool COUNT>
 __device__ __forceinline__ void trav_step(WalkRsrc walk, V3 o, V3 d, V3 inv, Trav& tr, Ctr& c) {
@@ -268,7 +287,11 @@ __device__ __forceinline__ void trav_step(WalkRsrc walk, V3 o, V3 d, V3 inv, Tra
 // C and D stay 128-bit register tuples from the load to the test (as scalars the allocator scattered them and
 // copied all eight back and forth on every step).
 struct ParkedLeaf { float v0x; u32x4 C, D; int info; bool parked; };
+#ifdef DR_HOST_BUILD
+__device__ __forceinline__ u32x4 ld_unit_raw(WalkRsrc r, unsigned byte_off) { return host_buffer_load_b128(r, byte_off); }
+#else
 __device__ __forceinline__ u32x4 ld_unit_raw(WalkRsrc r, unsigned byte_off) { return __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0); }
+#endif
 
 template <bool COUNT>
 __device__ __forceinline__ void trav_step_park(WalkRsrc walk, V3 o, V3 inv, Trav& tr, ParkedLeaf& pk, Ctr& c) {
@@ -311,6 +334,7 @@ constexpr int WAVE_LDS_DWORDS = 24 * 64;  // per-wave LDS region of the persiste
 constexpr int WIDE_STASH = 10;             // phase stash of the WIDE persistent kernel, dwords per lane (behind the WIDE_STACK stack words)
 constexpr int COOP_STACK = WAVE_LDS_DWORDS;   // node stack entries; a deeper frontier falls back to the plain walk
 
+#ifndef DR_HOST_BUILD          // wave-level code: not part of the host build
 __device__ __forceinline__ float wave_min_f32(float v) {
   for (int off = 32; off > 0; off >>= 1) v = __builtin_fminf(v, __shfl_xor(v, off, 64));
   return v;
@@ -384,6 +408,7 @@ __device__ __forceinline__ bool coop_closest_hit(const DevPair* __restrict__ pai
   out.slot = best_slot == 0x7fffffff ? -1 : best_slot;
   return true;
 }
+#endif
 
 // ------------------------------------------------------------------ wide walk
 // hit() K:468-512 over the 4-way tree of wide_builder.cpp (device_layout.h "wide walk").  The answer is the
@@ -503,7 +528,9 @@ __device__ __forceinline__ WideRec wide_fetch(WalkRsrc wide, int node) {
     _Pragma("unroll") for (int k = 0; k < DR_PAD_VMEM; k++) padm[k] = ld_unit_raw(wide, off + 64u * (unsigned)(k + 1));
     _Pragma("unroll") for (int k = 0; k < DR_PAD_VMEM; k++) asm volatile("" :: "v"(padm[k])); }
 #endif
+#ifndef DR_HOST_BUILD
   asm volatile("" : "+v"(r.A), "+v"(r.B), "+v"(r.C), "+v"(r.D));
+#endif
   return r;
 }
 
@@ -575,7 +602,11 @@ __device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, float pmax, V3 o,
   return best;
 }
 
+#ifdef DR_HOST_BUILD
+__device__ __forceinline__ bool first_active_lane() { return true; }      // a "wave" of one lane
+#else
 __device__ __forceinline__ bool first_active_lane() { return __lane_id() == (unsigned)__ffsll((long long)__ballot(1)) - 1u; }
+#endif
 
 template <bool COUNT>
 __device__ __forceinline__ Hit closest_hit_threaded(WalkRsrc walk, V3 o, V3 d, Ctr& c) {
