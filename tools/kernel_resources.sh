@@ -1,11 +1,13 @@
 #!/bin/bash
-# VGPRs / spills / LDS of every kernel in context.hip (compiles with -save-temps into /tmp/kres): tools/kernel_resources.sh [grep pattern] [extra flags]
+# VGPRs / spills / LDS of every kernel of one translation unit (compiles with -save-temps into /tmp/kres):
+#   tools/kernel_resources.sh [unit=kernels_render] [grep pattern] [extra flags]
 R=$(cd "$(dirname "$0")/.." && pwd)
+U=${1:-kernels_render}
 rm -rf /tmp/kres && mkdir -p /tmp/kres && cd /tmp/kres
-/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=0 $2 --offload-arch=gfx950 -c $R/dogeray_amd/csrc/context.hip -o ctx.o -save-temps 2>/dev/null
-python3 - "$1" <<'PY'
+/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=0 $3 --offload-arch=gfx950 -c $R/dogeray_amd/csrc/$U.hip -o u.o -save-temps 2>/dev/null
+python3 - "$2" "$U" <<'PY'
 import re, sys
-t = open('/tmp/kres/context-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+t = open('/tmp/kres/%s-hip-amdgcn-amd-amdhsa-gfx950.s' % sys.argv[2]).read()
 pat = sys.argv[1] if len(sys.argv) > 1 else ''
 for m in re.finditer(r'- \.agpr_count:.*?\.wavefront_size:', t, re.S):
     b = m.group(0)
