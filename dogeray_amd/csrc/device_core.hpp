@@ -331,6 +331,9 @@ __device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk
 // (equal t goes to the lower slot = the leaf the reference's walk reaches first).  Used only while a
 // launch drains (persistent kernel): idle lanes shorten the few long rays that set the launch time.
 constexpr int WAVE_LDS_DWORDS = 24 * 64;  // per-wave LDS region of the persistent kernel (6 KiB): phase stash / cooperative stack
+#ifndef DR_LDS_STACK
+#define DR_LDS_STACK WIDE_STACK      // stack words per lane the persistent kernel keeps in LDS.  Experiment builds (tools/exp_variant.sh -DDR_LDS_STACK=8 -DDR_LEAN_OCC=8)
+#endif                               // shrink it to make room for more waves per CU -- for TIMING only: deeper words are dropped there, frames are wrong
 constexpr int WIDE_STASH = 10;             // phase stash of the WIDE persistent kernel, dwords per lane (behind the WIDE_STACK stack words)
 constexpr int COOP_STACK = WAVE_LDS_DWORDS;   // node stack entries; a deeper frontier falls back to the plain walk
 
@@ -551,7 +554,7 @@ __device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv
     const unsigned base = r.A.w & 0xffffffu, leafmask = (r.B.w >> 4) & 15u;
     const unsigned rest = mask & ~(1u << near);
     if (rest != 0u) {
-      if (ws.top != 0u) { if (ws.sp < WIDE_STACK) { stack[ws.sp * 64] = (int)ws.top; ws.sp++; } }   // the host bounds the depth; the guard only protects LDS
+      if (ws.top != 0u) { if (ws.sp < DR_LDS_STACK) { stack[ws.sp * 64] = (int)ws.top; ws.sp++; } }   // the host bounds the depth; the guard only protects LDS
       ws.top = (base << 8) | (leafmask << 4) | rest;
     }
     tr.node = (int)(((base + (unsigned)near) << 1) | ((leafmask >> near) & 1u));

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   //    the wide walk's work sharing.  The wide walk's own stack (WIDE_STACK words per lane) sits in front of the stash.
   // WIDE && COOP: three more words per lane behind the stash -- the shared best hit (64-bit key) and the number of helper lanes of
   // a ray whose subtrees have been handed out (drain phase, below)
-  constexpr int SHARE_OFF = (WIDE_STACK + WIDE_STASH) * 64;
-  constexpr int REGION = WIDE ? (WIDE_STACK + WIDE_STASH + (COOP ? 3 : 0)) * 64 : WAVE_LDS_DWORDS;
+  constexpr int SHARE_OFF = (DR_LDS_STACK + WIDE_STASH) * 64;
+  constexpr int REGION = WIDE ? (DR_LDS_STACK + WIDE_STASH + (COOP ? 3 : 0)) * 64 : WAVE_LDS_DWORDS;
   __shared__ __attribute__((aligned(16))) int wave_lds[4 * REGION];
   int* const my_lds = wave_lds + (threadIdx.x >> 6) * REGION;
   int* const my_stack = my_lds + lane;                             // WIDE: word k of this lane's stack at my_stack[k * 64]
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked) && !waits_for_helpers;
       if (COUNT) n_shaded += __popcll(__ballot(shade_me));
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
-      float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? WIDE_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
+      float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? DR_LDS_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
       if (WIDE) {
         // ten words (26 KiB of LDS per workgroup with the stack: six workgroups per CU): the stack pointer shares a word with the frame
         // of the batch, x + 1 (0: no pixel) with y -- make_params bounds the frame size
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (n == 0) break;
       {
         if (DR_WAVE_LOG_DETAIL) d_given += (unsigned long long)n;
-        int* const xch = my_lds + WIDE_STACK * 64;                 // the phase stash is free between phases: 8 words per hand-over
+        int* const xch = my_lds + DR_LDS_STACK * 64;                 // the phase stash is free between phases: 8 words per hand-over
         const int rank_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(givers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)givers, 0u));
         const int rank_i = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
         if (can_give && rank_g < n) {
@@ -607,11 +607,14 @@ bool launch_wide_lean6(hipStream_t stream, const RenderParams& P_in, const Persi
   RenderParams P = P_in;
   const long long work = (long long)P.ncols * P.gy * P.batch;
   if (P.coop_steps > 0 && work < (long long)cfg.coop_tiles_per_wave * cfg.num_cus * 5 * 4) return false;      // a short launch: work-sharing build
-  int blocks = cfg.num_cus * 6;
+#ifndef DR_LEAN_OCC
+#define DR_LEAN_OCC 6      // (experiment builds: 7 or 8 with -DDR_LDS_STACK=10 / 8, timing only)
+#endif
+  int blocks = cfg.num_cus * DR_LEAN_OCC;
   if ((long long)blocks * 4 > work) blocks = (int)((work + 3) / 4);
   if (!DR_WAVE_LOG_DETAIL || blocks * 4 > WAVE_LOG_WAVES) P.wave_log = nullptr;      // only experiment builds log the lean kernel's waves
   log_waves = P.wave_log ? blocks * 4 : 0;
-  hipLaunchKernelGGL((render_persistent_kernel<false, 6, 32, 16, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
+  hipLaunchKernelGGL((render_persistent_kernel<false, DR_LEAN_OCC, 32, 16, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
   return true;
 }
 
