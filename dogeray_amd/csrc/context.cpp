@@ -70,7 +70,7 @@ struct dr_context {
   int kernel = DR_KERNEL_PERSISTENT;
   int occupancy = 6;        // waves per SIMD the kernel is built and launched for (persistent: 4, 5, or 6 = six for the lean wide build and five for the others; tile kernel: 4 or 6)
   int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
-  int park_min = 16;        // persistent kernel: leaf steps (parked leaves) once this many lanes stand at one (0 = on the spot)
+  int park_min = 20;        // persistent kernel: leaf steps (parked leaves) once this many lanes stand at one (0 = on the spot)
   int unroll = 2;           // persistent kernel: node steps per loop iteration
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
   int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural, -1 = all by cost)
@@ -315,7 +315,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   if (name == "kernel") { if (v != DR_KERNEL_TILE && v != DR_KERNEL_PERSISTENT) goto bad; c->kernel = v; }
   else if (name == "occupancy") { if (v != 4 && v != 5 && v != 6) goto bad; c->occupancy = v; }
   else if (name == "trav_min") { if (v != 32 && v != 48) goto bad; c->trav_min = v; }
-  else if (name == "park_min") { if (v != 0 && v != 8 && v != 16) goto bad; c->park_min = v; }
+  else if (name == "park_min") { if (v != 0 && v != 8 && v != 16 && v != 20) goto bad; c->park_min = v; }
   else if (name == "heavy_factor") { if (v < -1 || v > 1000) goto bad; c->heavy_factor = v; c->order_valid = false; }
   else if (name == "coop_steps") { if (v < 0) goto bad; c->coop_steps = v; }
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }

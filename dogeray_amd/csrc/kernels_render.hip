@@ -72,6 +72,12 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // code in the loop, so launches whose queue is long enough to hide their tail use the lean build (80 VGPRs and 26 KiB of LDS at
 // OCC = 6: six waves per SIMD; launch_persistent / launch_wide_lean6 pick).
 
+#ifndef DR_LEAF_IF_MORE
+#define DR_LEAF_IF_MORE 0
+#endif
+#ifndef DR_EXCLUSIVE_STEPS
+#define DR_EXCLUSIVE_STEPS 1      // wide walk: an iteration's step is a leaf step OR a node step (0: both kinds of lanes step together, as in round 2)
+#endif
 template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE, bool COOP = true>
 __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, const int* __restrict__ region_start,
@@ -463,9 +469,26 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       const bool at_leaf = tr.node >= 0 && (tr.node & 1);
       const unsigned long long leaves = __ballot(at_leaf);
       const unsigned long long nodes = __ballot(tr.node >= 0 && !(tr.node & 1));
-      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes == 0ull || cur_tile >= ntiles || held);
-      if (COUNT) { n_leafstep += do_leaves; n_nodestep += nodes != 0ull; }
-      if (tr.node >= 0 && (!at_leaf || do_leaves)) {
+      // A leaf step and a node step taken together share their fetch round trip, but each then runs for about half the wave (the two are
+      // different code).  The kernel is bound by instruction issue, not by latency (seven waves per SIMD are no faster than six,
+      // profiles/r3_h), so outside the drain the node lanes sit out a leaf step and the node steps in between run fuller:
+      // 0.626 -> 0.598 ms/frame with park_min 20 (profiles/r3_i_exclusive_steps.txt; DR_EXCLUSIVE_STEPS 0 = round 2's merged steps).
+#ifdef DR_PARK_THR
+      constexpr int park_thr = DR_PARK_THR;            // experiment builds
+#else
+      constexpr int park_thr = PARK_MIN > 0 ? PARK_MIN : 1;
+#endif
+      const bool draining = cur_tile >= ntiles || held;
+#if DR_LEAF_IF_MORE      // experiment: ... or as soon as more lanes stand at leaves than at nodes
+      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= park_thr || __popcll(leaves) >= __popcll(nodes) + DR_LEAF_IF_MORE - 1 || draining);
+#else
+      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= park_thr || nodes == 0ull || draining);
+#endif
+      // (not in the work-sharing build of short launches: what it gains in their bulk it loses in their tail, 1.10 against 1.075 ms for a single frame)
+      constexpr bool EXCLUSIVE = DR_EXCLUSIVE_STEPS && !COOP;
+      const bool do_nodes = !EXCLUSIVE || !do_leaves || draining;
+      if (COUNT) { n_leafstep += do_leaves; n_nodestep += nodes != 0ull && do_nodes; }
+      if (tr.node >= 0 && (at_leaf ? do_leaves : do_nodes)) {
         if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
         const WideRec r = wide_fetch(walk, tr.node);
         if (at_leaf) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, tr, ws, my_stack, c);
@@ -477,9 +500,14 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         const bool at_leaf2 = tr.node >= 0 && (tr.node & 1);
         const unsigned long long leaves2 = __ballot(at_leaf2);
         const unsigned long long nodes2 = __ballot(tr.node >= 0 && !(tr.node & 1));
-        const bool do_leaves2 = leaves2 != 0ull && ((int)__popcll(leaves2) >= (PARK_MIN > 0 ? PARK_MIN : 1) || nodes2 == 0ull || cur_tile >= ntiles || held);
-        if (COUNT) { n_leafstep += do_leaves2; n_nodestep += nodes2 != 0ull; }
-        if (tr.node >= 0 && (!at_leaf2 || do_leaves2)) {
+#if DR_LEAF_IF_MORE
+        const bool do_leaves2 = leaves2 != 0ull && ((int)__popcll(leaves2) >= park_thr || __popcll(leaves2) >= __popcll(nodes2) + DR_LEAF_IF_MORE - 1 || draining);
+#else
+        const bool do_leaves2 = leaves2 != 0ull && ((int)__popcll(leaves2) >= park_thr || nodes2 == 0ull || draining);
+#endif
+        const bool do_nodes2 = !EXCLUSIVE || !do_leaves2 || draining;
+        if (COUNT) { n_leafstep += do_leaves2; n_nodestep += nodes2 != 0ull && do_nodes2; }
+        if (tr.node >= 0 && (at_leaf2 ? do_leaves2 : do_nodes2)) {
           if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
           const WideRec r = wide_fetch(walk, tr.node);
           if (at_leaf2) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, tr, ws, my_stack, c);
@@ -603,7 +631,7 @@ int launch_persistent(hipStream_t stream, const RenderParams& P_in, const Persis
 // Six waves per SIMD (occupancy 6): only the wide walk's lean build fits -- 80 VGPRs and 26 KiB of LDS per workgroup -- and only with the
 // default thresholds; every other launch (counting build, work-sharing build of short launches, other tunings) runs five.
 bool launch_wide_lean6(hipStream_t stream, const RenderParams& P_in, const PersistentCfg& cfg, unsigned* counter, const int* order, const int* rstart, unsigned* pixel_cost, int& log_waves) {
-  if (cfg.traversal != DR_TRAVERSAL_WIDE || cfg.count || cfg.trav_min != 32 || cfg.park_min != 16 || cfg.unroll != 2) return false;
+  if (cfg.traversal != DR_TRAVERSAL_WIDE || cfg.count || cfg.trav_min != 32 || cfg.park_min != 20 || cfg.unroll != 2) return false;
   RenderParams P = P_in;
   const long long work = (long long)P.ncols * P.gy * P.batch;
   if (P.coop_steps > 0 && work < (long long)cfg.coop_tiles_per_wave * cfg.num_cus * 5 * 4) return false;      // a short launch: work-sharing build
@@ -614,7 +642,10 @@ bool launch_wide_lean6(hipStream_t stream, const RenderParams& P_in, const Persi
   if ((long long)blocks * 4 > work) blocks = (int)((work + 3) / 4);
   if (!DR_WAVE_LOG_DETAIL || blocks * 4 > WAVE_LOG_WAVES) P.wave_log = nullptr;      // only experiment builds log the lean kernel's waves
   log_waves = P.wave_log ? blocks * 4 : 0;
-  hipLaunchKernelGGL((render_persistent_kernel<false, DR_LEAN_OCC, 32, 16, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
+#ifndef DR_LEAN_UNROLL
+#define DR_LEAN_UNROLL 2   // (experiment builds: steps per loop iteration of the lean kernel)
+#endif
+  hipLaunchKernelGGL((render_persistent_kernel<false, DR_LEAN_OCC, 32, 20, DR_LEAN_UNROLL, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
   return true;
 }
 
@@ -625,6 +656,7 @@ int launch_persistent_occ(hipStream_t stream, const RenderParams& P, const Persi
   switch (key) {
     case 13208: return launch_persistent<OCC, 32, 8, 2>(stream, P, cfg, counter, order, rstart, pcost);
     case 13216: return launch_persistent<OCC, 32, 16, 2>(stream, P, cfg, counter, order, rstart, pcost);
+    case 13220: return launch_persistent<OCC, 32, 20, 2>(stream, P, cfg, counter, order, rstart, pcost);
     case 23208: return launch_persistent<OCC, 32, 8, 3>(stream, P, cfg, counter, order, rstart, pcost);
     case 3200: return launch_persistent<OCC, 32, 0>(stream, P, cfg, counter, order, rstart, pcost);
     case 4800: return launch_persistent<OCC, 48, 0>(stream, P, cfg, counter, order, rstart, pcost);

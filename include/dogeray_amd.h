@@ -160,7 +160,7 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   ("order_follows_camera", default 1)
  *   "occupancy"     waves per SIMD.  Persistent kernel: 6 (default: six for the wide walk's lean build of long launches, five for
  *                   every other build), 5 or 4; tile kernel: 4 or 6
- *   "trav_min"      32 or 48;  "park_min"  0, 8 or 16 (default);  "unroll"  1, 2 (default) or 3   (persistent kernel scheduling)
+ *   "trav_min"      32 or 48;  "park_min"  0, 8, 16 or 20 (default);  "unroll"  1, 2 (default) or 3   (persistent kernel scheduling)
  *   "xcd_regions"   1 (default): one tile queue per XCD, each an image band, with stealing; 0: one queue
  *   "heavy_factor"  with feedback: tiles that cost more than this many times the mean start first (most expensive
  *                   first), all others keep their natural order (default 1: the above-average tiles; 0: no tile is

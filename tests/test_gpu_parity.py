@@ -398,7 +398,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
     combos = [{"kernel": 0, "occupancy": 4}, {"kernel": 0, "occupancy": 6}, {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 8},
               {"kernel": 1, "occupancy": 5, "trav_min": 48, "park_min": 0}, {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 16},
               {"kernel": 1, "occupancy": 4, "trav_min": 48, "park_min": 8, "feedback": 0}, {"kernel": 1, "batch_frames": 3},
-              {"kernel": 1, "trav_min": 32, "park_min": 8, "unroll": 1}, {"kernel": 1, "unroll": 3}, {"kernel": 1, "park_min": 16, "unroll": 2},
+              {"kernel": 1, "trav_min": 32, "park_min": 8, "unroll": 1}, {"kernel": 1, "unroll": 3}, {"kernel": 1, "park_min": 16, "unroll": 2}, {"kernel": 1, "park_min": 20, "occupancy": 5},
               {"kernel": 1, "batch_frames": 1, "coop_steps": 1, "coop_lanes": 64}, {"kernel": 1, "batch_frames": 1, "coop_steps": 0},
               {"kernel": 1, "batch_frames": 2, "coop_steps": 16, "coop_lanes": 4},
               {"kernel": 1, "batch_frames": 1, "split_parts": 4, "split_steps": 32, "coop_rounds": 4, "split_waves": 50}, {"kernel": 1, "batch_frames": 3, "split_parts": 8, "split_steps": 16},
@@ -420,10 +420,10 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         if base is None:
             base = acc
         assert np.array_equal(acc, base), opts
-    for k, v in {"kernel": 1, "occupancy": 6, "trav_min": 32, "park_min": 16, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 2, "coop_lanes": 8, "coop_rounds": 2,
+    for k, v in {"kernel": 1, "occupancy": 6, "trav_min": 32, "park_min": 20, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 2, "coop_lanes": 8, "coop_rounds": 2,
                  "split_parts": 4, "split_steps": 400, "split_waves": 12, "coop_tiles_per_wave": 32, "paired": 0, "roles": 0}.items():
         ctx.set_option(k, v)
-    assert ctx.get_option("park_min") == 16 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
+    assert ctx.get_option("park_min") == 20 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
     with pytest.raises(dr.DogerayError):
         ctx.set_option("park_min", 7)
     with pytest.raises(dr.DogerayError):
