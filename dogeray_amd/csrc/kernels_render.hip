@@ -485,7 +485,10 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= park_thr || nodes == 0ull || draining);
 #endif
       // (not in the work-sharing build of short launches: what it gains in their bulk it loses in their tail, 1.10 against 1.075 ms for a single frame)
-      constexpr bool EXCLUSIVE = DR_EXCLUSIVE_STEPS && !COOP;
+#ifndef DR_EXCLUSIVE_COOP
+#define DR_EXCLUSIVE_COOP 0       // (experiment builds: exclusive steps in the work-sharing build's bulk too)
+#endif
+      constexpr bool EXCLUSIVE = DR_EXCLUSIVE_STEPS && (!COOP || DR_EXCLUSIVE_COOP);
       const bool do_nodes = !EXCLUSIVE || !do_leaves || draining;
       if (COUNT) { n_leafstep += do_leaves; n_nodestep += nodes != 0ull && do_nodes; }
       if (tr.node >= 0 && (at_leaf ? do_leaves : do_nodes)) {
