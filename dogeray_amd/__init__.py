@@ -106,6 +106,7 @@ _API = [
     ("dr_context_synchronize", C.c_int, [_VP]),
     ("dr_pipeline_submit", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.POINTER(C.c_uint64)]),
     ("dr_pipeline_wait", C.c_int, [_VP, C.c_uint64, _VP]),
+    ("dr_pipeline_image", C.c_int, [_VP, C.c_uint64, C.POINTER(_VP)]),
     ("dr_render_accumulate_pipelined", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_uint64, C.c_int]),
     ("dr_context_stream", C.c_int, [_VP, C.POINTER(_VP)]),
     ("dr_accum_pack_stripe", C.c_int, [_VP, C.c_int, C.POINTER(_VP), C.POINTER(C.c_uint64)]),
@@ -351,12 +352,21 @@ class Context:
         _check(lib().dr_pipeline_submit(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1), int(present_divide_by), C.byref(t)))
         return int(t.value)
 
-    def pipeline_wait(self, ticket, want_image=False):
-        """Waits for a submitted frame; with want_image the RGB8 image [H, W, 3] of exactly the frames up to that ticket."""
+    def pipeline_wait(self, ticket, want_image=False, in_place=False):
+        """Waits for a submitted frame; with want_image the RGB8 image [H, W, 3] of exactly the frames up to that ticket (in_place: a
+        read-only view of the library's pinned download buffer, valid until pipe_streams + 1 more frames have been submitted)."""
         if not want_image:
             _check(lib().dr_pipeline_wait(self._h, int(ticket), None))
             return None
         W, H, _ = self._acc_shape
+        if in_place:
+            _check(lib().dr_pipeline_wait(self._h, int(ticket), None))
+            ptr = _VP()
+            _check(lib().dr_pipeline_image(self._h, int(ticket), C.byref(ptr)))
+            buf = (C.c_uint8 * (W * H * 3)).from_address(ptr.value)
+            img = np.frombuffer(buf, dtype=np.uint8).reshape(H, W, 3)
+            img.flags.writeable = False
+            return img
         img = np.empty((H, W, 3), dtype=np.uint8)
         _check(lib().dr_pipeline_wait(self._h, int(ticket), _p(img)))
         return img

@@ -855,6 +855,17 @@ int dr_pipeline_wait(dr_context* c, uint64_t ticket, uint8_t* out_rgb8) {
   return DR_OK;
 }
 
+int dr_pipeline_image(dr_context* c, uint64_t ticket, const uint8_t** rgb8) {
+  if (!c || !c->acc_stream || !rgb8) { set_error("pipeline: nothing submitted, or null argument"); return DR_ERR_INVALID; }
+  const uint64_t depth = (uint64_t)c->pipe_streams + 1;
+  if (ticket >= c->pipe_next || ticket + depth < c->pipe_next) { set_error("pipeline: ticket not in flight (the pipeline keeps pipe_streams + 1 frames)"); return DR_ERR_INVALID; }
+  const int slot = (int)(ticket % depth);
+  if (!c->pipe_waited[slot]) { set_error("pipeline: dr_pipeline_wait(ticket) comes first"); return DR_ERR_INVALID; }
+  if (!c->pipe_div[slot]) { set_error("pipeline: that frame was submitted without a present"); return DR_ERR_INVALID; }
+  *rgb8 = c->pipe_rgb_host[slot];
+  return DR_OK;
+}
+
 int dr_render_accumulate_pipelined(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
                                    uint64_t seed_stride, int nframes) {
   if (!c || nframes < 0) { set_error("bad argument"); return DR_ERR_INVALID; }

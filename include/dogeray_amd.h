@@ -230,6 +230,10 @@ int dr_context_synchronize(dr_context* c);
 int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
                        int present_divide_by, uint64_t* ticket);
 int dr_pipeline_wait(dr_context* c, uint64_t ticket, uint8_t* out_rgb8);
+/* the presented image of a ticket that has been waited for, in place: a pointer into the library's pinned download buffer (W * H * 3 bytes, row-major
+ * RGB8), valid until pipe_streams + 1 more frames have been submitted -- for a caller that uploads it to a texture anyway (K:2243-2275) and would
+ * rather not copy 6 MB per frame twice */
+int dr_pipeline_image(dr_context* c, uint64_t ticket, const uint8_t** rgb8);
 int dr_render_accumulate_pipelined(dr_context* c, const float settings13[13], int W, int H, float background,
                                    uint64_t frame_seed, uint64_t seed_stride, int nframes);
 /* The HIP stream (hipStream_t) every launch of this context is queued on, for callers that order their own device work

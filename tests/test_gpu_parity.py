@@ -281,6 +281,11 @@ def test_pipelined_present_loop(dr, orc, ctx, synth, tmp_path):
         want = np.clip(quot, 0, 255).astype(np.uint8).transpose(1, 0, 2)
         assert np.array_equal(img, want), "image shown after iteration %d" % it
     assert np.array_equal(ctx.accum_read(), sums[-1])
+    # the presented image in place (dr_pipeline_image): the same bytes as the copy
+    t = ctx.pipeline_submit(dr.pack_settings13(s, 1), 256, 256, s.background, 99, present_divide_by=5)
+    view = ctx.pipeline_wait(t, want_image=True, in_place=True)
+    assert view.shape == (256, 256, 3) and not view.flags.writeable
+    assert np.array_equal(view, ctx.accum_present(5))
     # and on a larger frame with textures, without presents, against the batched accumulation
     ps2 = dr.Scene.load(os.path.join(synth["dir"], "matball.rts"), synth["tex"])
     ps2.build_bvh()
