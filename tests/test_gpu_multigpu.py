@@ -124,6 +124,21 @@ def test_native_host_application_with_gpus(dr, synth, tmp_path):
     assert outs[0] == outs[1] and len(outs[0]) > 1000
 
 
+def test_native_host_application_pipelined_present_loop(dr, synth, tmp_path):
+    """csrc/dogeray_main.cpp --group 1: one frame per displayed image, through dr_pipeline_submit / dr_pipeline_wait (frame k + 1 queued
+    before frame k's image is waited for).  The last image shown is clamp(sum of all frames / count), so it must equal the image of
+    a run that renders the same frames in batches of 5."""
+    exe = os.path.join(ROOT, "dogeray_amd", "bin", "dogeray")
+    scene = os.path.join(synth["dir"], "city_small.rts")
+    outs = []
+    for group in (1, 5):
+        out = str(tmp_path / ("loop%d.ppm" % group))
+        r = subprocess.run([exe, scene, "--textures", synth["tex"], "--frames", "13", "--group", str(group), "--out", out, "--quiet"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        outs.append(open(out, "rb").read())
+    assert outs[0] == outs[1] and len(outs[0]) > 1000
+
+
 def test_stripe_gatherer_with_a_stand_in_collective(dr, scene, monkeypatch):
     """multigpu.StripeGatherer (bench.py --gpus N on RCCL) for two ranks in ONE process: torch.distributed.gather is replaced
     by a copy between the two ranks' buffers (RCCL refuses two ranks on one device), everything else -- pack kernel on the
