@@ -132,6 +132,7 @@ _API = [
     ("dr_kat_rng", C.c_int, [_VP, C.c_uint64, C.c_int, _VP]),
     ("dr_kat_aabb", C.c_int, [_VP, C.c_int] + [_VP] * 6),
     ("dr_kat_tri", C.c_int, [_VP, C.c_int] + [_VP] * 6),
+    ("dr_kat_node_planes", C.c_int, [_VP, C.c_int] + [_VP] * 5),
     ("dr_kat_sphere", C.c_int, [_VP, C.c_int] + [_VP] * 5),
     ("dr_kat_optics", C.c_int, [_VP, C.c_int] + [_VP] * 6),
     ("dr_kat_hit", C.c_int, [_VP, C.c_int] + [_VP] * 5),
@@ -484,6 +485,14 @@ class Context:
         t = np.zeros(n, dtype=np.float32)
         _check(lib().dr_kat_tri(self._h, n, _p(o), _p(d), _p(v0), _p(v1), _p(v2), _p(t)))
         return t
+
+    def kat_node_planes(self, w, a, b):
+        """(t_mix, t_cvt), 4 per word: the node test's plane arithmetic through v_fma_mix_f32 / through a conversion and an fma"""
+        w = np.ascontiguousarray(w, np.uint32); a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        n = len(w)
+        t1 = np.empty(n * 4, np.float32); t2 = np.empty(n * 4, np.float32)
+        _check(lib().dr_kat_node_planes(self._h, n, _p(w), _p(a), _p(b), _p(t1), _p(t2)))
+        return t1, t2
 
     def kat_sphere(self, o, d, c, r):
         o, d, c, r = map(_f32, (o, d, c, r))

@@ -1096,6 +1096,18 @@ int dr_kat_aabb(dr_context* c, int n, const float* o, const float* d, const floa
   return bdist.get(dist, (size_t)n);
 }
 
+int dr_kat_node_planes(dr_context* c, int n, const uint32_t* w, const float* a, const float* b, float* t_mix, float* t_cvt) {
+  KAT_PRE(n);
+  DevBuf<uint32_t> bw;
+  DevBuf<float> ba, bb, b1, b2;
+  KAT_DO(bw.alloc((size_t)n)); KAT_DO(ba.alloc((size_t)n)); KAT_DO(bb.alloc((size_t)n)); KAT_DO(b1.alloc((size_t)n * 4)); KAT_DO(b2.alloc((size_t)n * 4));
+  KAT_DO(bw.put(w, (size_t)n)); KAT_DO(ba.put(a, (size_t)n)); KAT_DO(bb.put(b, (size_t)n));
+  launch_kat_node_planes(c->stream, n, bw.p, ba.p, bb.p, b1.p, b2.p);
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  KAT_DO(b1.get(t_mix, (size_t)n * 4));
+  return b2.get(t_cvt, (size_t)n * 4);
+}
+
 int dr_kat_tri(dr_context* c, int n, const float* o, const float* d, const float* v0, const float* v1, const float* v2, float* t) {
   KAT_PRE(n);
   DevBuf<float> bo, bd, b0, b1, b2, bt;

@@ -219,7 +219,10 @@ struct Ctr { unsigned rays, V, L, S, T, samples, trav_slots, ray_slots; };   // 
 // different rays (lanes re-armed while their neighbours are still walking).
 struct Trav { int node; float best_t; int best_slot; };   // node: link to visit next, < 0 = walk finished
 
-__device__ __forceinline__ void trav_begin(Trav& tr) { tr.node = 0; tr.best_t = 10000000.0f; tr.best_slot = -1; }
+// "No hit yet" is t = 10000: singlehit only returns distances below 10000 (K:449) and aabb2's exit distance starts at 10000 (K:246), so every
+// comparison against the running best (box entry < best, t < best) comes out as with the 1e7 of hit() K:470 -- and the wide walk's node
+// test needs no min(best, 10000) of its own.
+__device__ __forceinline__ void trav_begin(Trav& tr) { tr.node = 0; tr.best_t = 10000.0f; tr.best_slot = -1; }
 
 // The walk array is read through a buffer descriptor with 128-bit buffer loads: the compiler may
 // not re-slice those into narrower / unaligned pieces (it does so with plain float4 loads: the box
@@ -448,9 +451,51 @@ __device__ __forceinline__ float ubyte_f(unsigned w, int k) { return (float)((w 
 #ifndef DR_WIDE_FOLD
 #define DR_WIDE_FOLD 1
 #endif
+// DR_NODE_V2 (default, round 3): the same folded test with fewer instructions per node step (152 -> 128 VALU):
+//  * a plane byte is read as the f16 DENORMAL byte * 2^-24 (half-word 0x00bb) and the node record stores scale * 2^24 (device_layout.h), so that
+//    v_fma_mix_f32 converts the byte on the fly: fma(byte * 2^-24, (scale * 2^24) * inv, b) is the SAME real number rounded once as
+//    fma(byte, scale * inv, b) -- one instruction per plane instead of a conversion and an fma, and two plane bytes are unpacked by one
+//    v_and / v_perm (the kernel runs with f16 denormals on, .amdhsa_float_denorm_mode_16_64 3; dr_kat_node_planes checks the instruction).
+//    Powers of two scale exactly as long as nothing overflows: |inv| <= 2^60 (clamped), scale <= 2^36 (wide_builder.cpp refuses larger
+//    grids), so a <= 2^120.
+//  * b = fma(origin, inv, -(fl(o * inv) +- m)) with the ray-only part precomputed by wide_ray(): 6 instructions instead of 12.  Its error
+//    against the real (origin - o) * inv is u |inv| (3 |o| + P) + 2 u m (was 2 u |inv| (P + |o|)); with the plane's own u |t| and the
+//    decode-and-slab side's u |inv| (3 P + 2 |o|) the sum is u |inv| (5 P + 6 |o|) + 3 u m < m = 8 u |inv| (P + |o|): still covered.
+//    o * inv could overflow for |o| > 2^67 where (origin - o) * inv did not: an axis with |o| >= 2^60 is left unconstrained (NaN margin).
+//  * the cap of the exit distance is the running best itself (trav_begin: "no hit yet" = 10000).
+#ifndef DR_NODE_V2
+#define DR_NODE_V2 1
+#endif
+#ifndef DR_NODE_BFOLD
+#define DR_NODE_BFOLD 1      // 0: b = (origin - o) * inv -+ m as before (three registers fewer, six instructions more)
+#endif
+#if DR_NODE_V2 && DR_NODE_BFOLD
+struct WideRay { V3 inv, on, of; };      // inv: clamped 1/direction; on / of: fl(o * inv) + m, fl(o * inv) - m (what the near / far planes subtract)
+#else
 struct WideRay { V3 inv, marg; };        // what the folded node test needs of a ray besides its origin
+#endif
+__device__ __forceinline__ WideRay wide_ray_none() {      // a lane without a ray
+  WideRay w;
+#if DR_NODE_V2 && DR_NODE_BFOLD
+  w.inv = w.on = w.of = mk(0, 0, 0);
+#else
+  w.inv = w.marg = mk(0, 0, 0);
+#endif
+  return w;
+}
 __device__ __forceinline__ WideRay wide_ray(V3 o, V3 inv, float pmax) {
   WideRay w;
+#if DR_NODE_V2 && DR_NODE_BFOLD
+  auto one = [pmax](float oa, float ia, float& ic, float& on, float& of) {
+    ic = __builtin_fminf(__builtin_fmaxf(ia, -0x1p60f), 0x1p60f);                    // NaN -> -2^60, and the margin below is NaN
+    const float k = __builtin_fmaf(pmax + __builtin_fabsf(oa), 0x1p-21f, 0x1p-40f);
+    const float ai = __builtin_fabsf(ic);
+    const float m = (ia == ia && ai > 0x1p-60f && __builtin_fabsf(oa) < 0x1p60f) ? ai * k : __builtin_nanf("");
+    const float p = oa * ic;
+    on = p + m; of = p - m;
+  };
+  one(o.x, inv.x, w.inv.x, w.on.x, w.of.x); one(o.y, inv.y, w.inv.y, w.on.y, w.of.y); one(o.z, inv.z, w.inv.z, w.on.z, w.of.z);
+#else
   auto one = [pmax](float oa, float ia, float& ic, float& m) {
     ic = __builtin_fminf(__builtin_fmaxf(ia, -0x1p60f), 0x1p60f);                    // NaN -> -2^60, and the margin below is NaN
     const float k = __builtin_fmaf(pmax + __builtin_fabsf(oa), 0x1p-21f, 0x1p-40f);
@@ -458,23 +503,71 @@ __device__ __forceinline__ WideRay wide_ray(V3 o, V3 inv, float pmax) {
     m = (ia == ia && ai > 0x1p-60f) ? ai * k : __builtin_nanf("");
   };
   one(o.x, inv.x, w.inv.x, w.marg.x); one(o.y, inv.y, w.inv.y, w.marg.y); one(o.z, inv.z, w.inv.z, w.marg.z);
+#endif
   return w;
 }
 
-__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, V3 o, V3 inv, V3 marg, float best_t, unsigned& near_key) {   // fold: inv = WideRay::inv
+#if DR_NODE_V2
+// The four plane bytes of a word as f16 denormals: (byte0, byte2) and (byte1, byte3), each pair in one register
+#ifdef DR_HOST_BUILD
+struct PlanePairs { unsigned even, odd; };
+__device__ __forceinline__ PlanePairs plane_pairs(unsigned w) { PlanePairs p; p.even = w & 0x00ff00ffu; p.odd = (w >> 8) & 0x00ff00ffu; return p; }
+__device__ __forceinline__ float plane_t(const PlanePairs& p, int k, float a, float b) {     // fma(byte_k * 2^-24, a, b), rounded once
+  const unsigned h = ((k & 1) ? p.odd : p.even) >> ((k & 2) ? 16 : 0) & 0xffffu;
+  return __builtin_fmaf((float)h * 0x1p-24f, a, b);
+}
+#else
+typedef _Float16 DrHalf2 __attribute__((ext_vector_type(2)));
+struct PlanePairs { DrHalf2 even, odd; };
+__device__ __forceinline__ PlanePairs plane_pairs(unsigned w) {
+  PlanePairs p;
+  p.even = __builtin_bit_cast(DrHalf2, w & 0x00ff00ffu);
+  p.odd = __builtin_bit_cast(DrHalf2, __builtin_amdgcn_perm(0u, w, 0x0c030c01u));      // bytes {1, zero, 3, zero} of w: one v_perm_b32
+  return p;
+}
+__device__ __forceinline__ float plane_t(const PlanePairs& p, int k, float a, float b) {     // v_fma_mix_f32: the f16 operand is widened inside the instruction
+  const _Float16 h = (k & 1) ? ((k & 2) ? p.odd.y : p.odd.x) : ((k & 2) ? p.even.y : p.even.x);
+  return __builtin_fmaf((float)h, a, b);
+}
+#endif
+#endif
+
+__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, V3 o, V3 inv_plain, const WideRay& wr, float best_t, unsigned& near_key) {
   const float ox = __uint_as_float(A.x), oy = __uint_as_float(A.y), oz = __uint_as_float(A.z);
-  const float sx = __uint_as_float(B.x), sy = __uint_as_float(B.y), sz = __uint_as_float(B.z);
+  const float sx24 = __uint_as_float(B.x), sy24 = __uint_as_float(B.y), sz24 = __uint_as_float(B.z);      // scale * 2^24
+  const V3 inv = DR_WIDE_FOLD ? wr.inv : inv_plain;
   // the plane entered first is `hi` for a negative direction (slab(): same rule, so the comparison stays plane by plane)
   const unsigned nxw = inv.x < 0.0f ? C.w : C.x, fxw = inv.x < 0.0f ? C.x : C.w;
   const unsigned nyw = inv.y < 0.0f ? D.x : C.y, fyw = inv.y < 0.0f ? C.y : D.x;
   const unsigned nzw = inv.z < 0.0f ? D.y : C.z, fzw = inv.z < 0.0f ? C.z : D.y;
+  unsigned mask = 0, key = 0xffffffffu;
+#if DR_WIDE_FOLD && DR_NODE_V2
+  const float tcap = best_t;
+  const float ax = sx24 * inv.x, ay = sy24 * inv.y, az = sz24 * inv.z;
+#if DR_NODE_BFOLD
+  (void)o;
+  const float bxn = __builtin_fmaf(ox, inv.x, -wr.on.x), bxf = __builtin_fmaf(ox, inv.x, -wr.of.x);
+  const float byn = __builtin_fmaf(oy, inv.y, -wr.on.y), byf = __builtin_fmaf(oy, inv.y, -wr.of.y);
+  const float bzn = __builtin_fmaf(oz, inv.z, -wr.on.z), bzf = __builtin_fmaf(oz, inv.z, -wr.of.z);
+#else
+  const float bx = (ox - o.x) * inv.x, by = (oy - o.y) * inv.y, bz = (oz - o.z) * inv.z;
+  const float bxn = bx - wr.marg.x, bxf = bx + wr.marg.x, byn = by - wr.marg.y, byf = by + wr.marg.y, bzn = bz - wr.marg.z, bzf = bz + wr.marg.z;
+#endif
+  const PlanePairs pnx = plane_pairs(nxw), pfx = plane_pairs(fxw), pny = plane_pairs(nyw), pfy = plane_pairs(fyw), pnz = plane_pairs(nzw), pfz = plane_pairs(fzw);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const float t0x = plane_t(pnx, k, ax, bxn), t1x = plane_t(pfx, k, ax, bxf);
+    const float t0y = plane_t(pny, k, ay, byn), t1y = plane_t(pfy, k, ay, byf);
+    const float t0z = plane_t(pnz, k, az, bzn), t1z = plane_t(pfz, k, az, bzf);
+#else
   const float tcap = __builtin_fminf(best_t, 10000.0f);
+  const float sx = sx24 * 0x1p-24f, sy = sy24 * 0x1p-24f, sz = sz24 * 0x1p-24f;
 #if DR_WIDE_FOLD
+  const V3 marg = wr.marg;
   const float ax = sx * inv.x, ay = sy * inv.y, az = sz * inv.z;
   const float bx = (ox - o.x) * inv.x, by = (oy - o.y) * inv.y, bz = (oz - o.z) * inv.z;
   const float bxn = bx - marg.x, bxf = bx + marg.x, byn = by - marg.y, byf = by + marg.y, bzn = bz - marg.z, bzf = bz + marg.z;
 #endif
-  unsigned mask = 0, key = 0xffffffffu;
 #pragma unroll
   for (int k = 0; k < 4; k++) {
 #if DR_WIDE_FOLD
@@ -489,6 +582,7 @@ __device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u3
     const float t0y = (ny - o.y) * inv.y, t1y = (fy - o.y) * inv.y;
     const float t0z = (nz - o.z) * inv.z, t1z = (fz - o.z) * inv.z;
 #endif
+#endif
     const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0x, t0y), t0z), 0.0f);
     const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fminf(t1x, t1y), t1z), tcap);
     // >= where slab() has > and <=: a superset, which is all an internal node needs
@@ -501,7 +595,7 @@ __device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u3
   return mask & (B.w & 15u);
 }
 
-// (t, slot) as one 64-bit key whose unsigned order is the lexicographic order of the pair (t is positive, or the 1e7 of
+// (t, slot) as one 64-bit key whose unsigned order is the lexicographic order of the pair (t is positive, or the 10000 of
 // "no hit yet" with slot -1 = the largest unsigned): what lanes that share one ray agree on with ds_min_u64
 __device__ __forceinline__ unsigned long long hit_key(float t, int slot) { return ((unsigned long long)__float_as_uint(t) << 32) | (unsigned)slot; }
 
@@ -545,7 +639,7 @@ __device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv
   _Pragma("unroll") for (int k = 0; k < DR_PAD_VALU; k++) asm volatile("v_or_b32 %0, 0, %0" : "+v"(tr.best_slot));
 #endif
   unsigned key;
-  const unsigned mask = wide_node_test(r.A, r.B, r.C, r.D, o, DR_WIDE_FOLD ? wr.inv : inv, wr.marg, tr.best_t, key);
+  const unsigned mask = wide_node_test(r.A, r.B, r.C, r.D, o, inv, wr, tr.best_t, key);
   if (mask != 0u) {
     // nearest entered child next; the others wait as one stack word.  An unused child slot (inverted box, valid bit
     // clear) can only pass on a degenerate grid or ray; if it even has the smallest key, take the lowest valid one.

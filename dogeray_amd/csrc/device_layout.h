@@ -35,8 +35,10 @@ constexpr int WALK_SLOT_BITS = 26;                    // slots < 2^26 (the walk 
 constexpr int WALK_KIND_SPHERE = 0, WALK_KIND_TRIANGLE = 1, WALK_KIND_NONE = 2;   // object type 0 / 2 / anything else
 
 // Wide walk (wide_builder.cpp): 64-byte records, a 4-way tree over the same leaves.
-//   node  {origin.xyz, 0x80000000 | index of first child} {scale.xyz, valid mask | leaf mask << 4}
-//         {lo.x, lo.y, lo.z, hi.x} {hi.y, hi.z, -, -}   each lo/hi word = one byte per child: plane = fmaf(byte, scale, origin)
+//   node  {origin.xyz, 0x80000000 | index of first child} {scale.xyz * 2^24, valid mask | leaf mask << 4}
+//         {lo.x, lo.y, lo.z, hi.x} {hi.y, hi.z, -, -}   each lo/hi word = one byte per child: plane = fmaf(byte, scale, origin);
+//         scale is a power of two in [2^-60, 2^36] and is stored times 2^24: the kernel reads a plane byte as the f16 denormal
+//         byte * 2^-24 (device_core.hpp wide_node_test)
 //   leaf  {min.xyz, slot | kind << 26} {max.xyz, v0.x} {v0.yz, e1.xy} {e1.z, e2.xyz}      (the walk array's leaf record)
 // A node's children are contiguous records.  The kernel keeps, per lane, the children of a node that were entered
 // but not yet visited as ONE stack word: first child's index << 8 | leaf mask << 4 | pending mask.

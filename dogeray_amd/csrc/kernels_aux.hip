@@ -213,6 +213,23 @@ __global__ void kat_aabb_kernel(int n, const float* o, const float* d, const flo
   bool h = slab(ld3(o + 3 * i), inv, mn + 3 * i, mx + 3 * i, t);
   hit[i] = h; dist[i] = h ? t : 0;
 }
+__global__ void kat_node_planes_kernel(int n, const uint32_t* w, const float* a, const float* b, float* t_mix, float* t_cvt) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+#if DR_NODE_V2
+  const PlanePairs p = plane_pairs(w[i]);
+  const float a24 = a[i] * 0x1p24f;
+#endif
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+#if DR_NODE_V2
+    t_mix[4 * i + k] = plane_t(p, k, a24, b[i]);
+#else
+    t_mix[4 * i + k] = __builtin_fmaf(ubyte_f(w[i], k), a[i], b[i]);
+#endif
+    t_cvt[4 * i + k] = __builtin_fmaf(ubyte_f(w[i], k), a[i], b[i]);
+  }
+}
 __global__ void kat_tri_kernel(int n, const float* o, const float* d, const float* v0, const float* v1, const float* v2, float* t) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -305,6 +322,9 @@ void launch_gather_probe(hipStream_t stream, const RenderParams& P, int blocks, 
 void launch_kat_rng(hipStream_t stream, uint64_t seed, int n, double* out) { hipLaunchKernelGGL(kat_rng_kernel, dim3(1), dim3(64), 0, stream, seed, n, out); }
 void launch_kat_aabb(hipStream_t stream, int n, const float* o, const float* d, const float* mn, const float* mx, int32_t* hit, float* dist) {
   hipLaunchKernelGGL(kat_aabb_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, o, d, mn, mx, hit, dist);
+}
+void launch_kat_node_planes(hipStream_t stream, int n, const uint32_t* w, const float* a, const float* b, float* t_mix, float* t_cvt) {
+  hipLaunchKernelGGL(kat_node_planes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, w, a, b, t_mix, t_cvt);
 }
 void launch_kat_tri(hipStream_t stream, int n, const float* o, const float* d, const float* v0, const float* v1, const float* v2, float* t) {
   hipLaunchKernelGGL(kat_tri_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n, o, d, v0, v1, v2, t);

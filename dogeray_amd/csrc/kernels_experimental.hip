@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256, OCC) void render_paired_kernel(RenderParams P,
   Trav tr; tr.node = -1; tr.best_t = 0; tr.best_slot = -1;
   WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
   V3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), inv = mk(0, 0, 0);
-  WideRay wr; wr.inv = wr.marg = mk(0, 0, 0);
+  WideRay wr = wide_ray_none();
   unsigned wsteps = 0;
   int cur = -1;                           // slot being walked, -1 none
   int st0 = PS_EMPTY, st1 = PS_EMPTY;     // state of this lane's two paths
@@ -299,7 +299,7 @@ __global__ __launch_bounds__((NT + NS) * 64, 4) void render_roles_kernel(RenderP
     Trav tr; tr.node = -1; tr.best_t = 0; tr.best_slot = -1;
     WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
     V3 wo = mk(0, 0, 0), wd = mk(0, 0, 0), inv = mk(0, 0, 0);
-    WideRay wr; wr.inv = wr.marg = mk(0, 0, 0);
+    WideRay wr = wide_ray_none();
     int pid = -1;                       // the path this lane walks for (index within the workgroup), -1 none
     unsigned my_tail[NS];               // this wave's hit rings: entries written so far (wave-uniform)
 #pragma unroll

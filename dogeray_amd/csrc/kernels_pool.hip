@@ -166,7 +166,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WPS) void render_pool_kernel(RenderP
         const WideRay wr = wide_ray(o, inv, P.wide_pmax);
         unsigned top = __float_as_uint(A3.x); int sp = __float_as_int(A3.y);
         unsigned key;
-        const unsigned mask = wide_node_test(r.A, r.B, r.C, r.D, o, DR_WIDE_FOLD ? wr.inv : inv, wr.marg, A0.w, key);
+        const unsigned mask = wide_node_test(r.A, r.B, r.C, r.D, o, inv, wr, A0.w, key);
         if (mask != 0u) {
           int near = (int)(key & 3u);
           near = ((mask >> near) & 1u) ? near : __builtin_ctz(mask);
@@ -293,7 +293,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WPS) void render_pool_kernel(RenderP
       }
       if (slot >= 0 && alive) {
         const V3 inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
-        *reinterpret_cast<float4*>(u0) = make_float4(path.rayo.x, path.rayo.y, path.rayo.z, 10000000.0f);                 // trav_begin
+        *reinterpret_cast<float4*>(u0) = make_float4(path.rayo.x, path.rayo.y, path.rayo.z, 10000.0f);                 // trav_begin
         *reinterpret_cast<float4*>(u1) = make_float4(path.raydir.x, path.raydir.y, path.raydir.z, __int_as_float(-1));
         *reinterpret_cast<float4*>(u2) = make_float4(inv.x, inv.y, inv.z, __int_as_float(0));
         *reinterpret_cast<float4*>(u3) = make_float4(__uint_as_float(0u), __int_as_float(0), __uint_as_float(steps), __int_as_float(pcode));

@@ -75,6 +75,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 #ifndef DR_LEAF_IF_MORE
 #define DR_LEAF_IF_MORE 0
 #endif
+#ifndef DR_PHASE_HOME
+#define DR_PHASE_HOME (!DR_WAVE_LOG_DETAIL)           // wide walk: colour, pixel, sample and frame live in the phase stash outside the phase (0: in registers, as before)
+#endif
 #ifndef DR_EXCLUSIVE_STEPS
 #define DR_EXCLUSIVE_STEPS 1      // wide walk: an iteration's step is a leaf step OR a node step (0: both kinds of lanes step together, as in round 2)
 #endif
@@ -100,6 +103,10 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   int* const my_stack = my_lds + lane;                             // WIDE: word k of this lane's stack at my_stack[k * 64]
   unsigned long long* const share_key = reinterpret_cast<unsigned long long*>(my_lds + (WIDE ? SHARE_OFF : 0));     // [64], WIDE && COOP only
   unsigned* const share_pend = reinterpret_cast<unsigned*>(my_lds + (WIDE ? SHARE_OFF : 0) + 128);                   // [64]
+  if (WIDE && DR_PHASE_HOME) {     // the phase-only state lives in the stash (see the phase): no pixel yet
+    int* const st0 = my_lds + DR_LDS_STACK * 64 + lane;
+    for (int k = 1; k < 8; k++) st0[k * 64] = 0;
+  }
   int share = -1;                  // -1: this lane walks a ray of its own, alone; 0..63: it helps that lane's ray; 64: its ray has helpers
   WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
   const int ntiles = P.ncols * P.gy;
@@ -132,7 +139,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   Trav tr; tr.node = -2; tr.best_t = 0; tr.best_slot = -1;
   Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
   V3 inv = mk(0, 0, 0), color = mk(0, 0, 0);
-  WideRay wr; wr.inv = wr.marg = mk(0, 0, 0);   // WIDE: clamped 1/direction and margins of the folded node test, a function of the lane's ray
+  WideRay wr = wide_ray_none();    // WIDE: clamped 1/direction and margins of the folded node test, a function of the lane's ray
   Xorwow rng; rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = rng.d = 0;
   int px = -1, py = 0, sample = 0, bounce = 0;
   int frame = 0;                   // frame of the batch the pixel in this slot belongs to
@@ -199,12 +206,19 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
       float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? DR_LDS_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
       if (WIDE) {
-        // ten words (26 KiB of LDS per workgroup with the stack: six workgroups per CU): the stack pointer shares a word with the frame
-        // of the batch, x + 1 (0: no pixel) with y -- make_params bounds the frame size
-        st[0 * 64] = __uint_as_float(ws.top); st[1 * 64] = __int_as_float(ws.sp | (frame << 8));
+        // ten words (26 KiB of LDS per workgroup with the stack: six workgroups per CU).  Words 2-7 (colour, x + 1 (0: no pixel) with y -- make_params
+        // bounds the frame size --, pixel code, sample) and the frame of the batch (upper half of word 1) are needed in this phase only: they LIVE
+        // here and are registers only between the read after shading and the write at the end of the phase (DR_PHASE_HOME; the walk loop has
+        // eight registers more for the node step).  What goes in now is the walk's state: stack top, stack pointer, step counts.
+        st[0 * 64] = __uint_as_float(ws.top);
+#if DR_PHASE_HOME
+        reinterpret_cast<unsigned char*>(st + 1 * 64)[0] = (unsigned char)ws.sp;
+#else
+        st[1 * 64] = __int_as_float(ws.sp | (frame << 16));
         st[2 * 64] = color.x; st[3 * 64] = color.y; st[4 * 64] = color.z;
         st[5 * 64] = __int_as_float(((px + 1) << 16) | py); st[6 * 64] = __int_as_float(pcode);
         st[7 * 64] = __int_as_float(sample);
+#endif
         st[8 * 64] = __uint_as_float(steps); st[9 * 64] = __uint_as_float(rstart);
         asm volatile("" ::: "memory");
       } else {
@@ -220,6 +234,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         asm volatile("" ::: "memory");           // the values must really travel through LDS (no forwarding in registers)
       }
       // ---- shade the lanes whose walk has finished
+      DR_MARK("phase_shade");
       bool ended = false;
       V3 radiance = mk(0, 0, 0);
       if (shade_me) {
@@ -234,12 +249,13 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           ended = true;
         }
       }
+      DR_MARK("phase_unstash");
       if (WIDE) {
         asm volatile("" ::: "memory");
         color = mk(st[2 * 64], st[3 * 64], st[4 * 64]);
         { const int xy = __float_as_int(st[5 * 64]); px = (int)((unsigned)xy >> 16) - 1; py = xy & 0xffff; }
         pcode = __float_as_int(st[6 * 64]);
-        frame = __float_as_int(st[1 * 64]) >> 8; sample = __float_as_int(st[7 * 64]);
+        frame = (int)((unsigned)__float_as_int(st[1 * 64]) >> 16); sample = __float_as_int(st[7 * 64]);
         steps = __float_as_uint(st[8 * 64]); rstart = __float_as_uint(st[9 * 64]);
       } else {
         asm volatile("" ::: "memory");
@@ -347,6 +363,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         need = __ballot(want_pixel);
       }
       // ---- start the next path of every lane that has a pixel and no path
+      DR_MARK("phase_camera");
       if (tr.node == -2 && px >= 0) {
         if (degenerate) {
           sample = 0x7fffffff;                     // nothing to trace: the pixel is stored as 0 next round
@@ -362,9 +379,19 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           fresh_ray = true;
         }
       }
+      DR_MARK("phase_restore");
       if (WIDE) {
         asm volatile("" ::: "memory");
         ws.top = __float_as_uint(st[0 * 64]); ws.sp = __float_as_int(st[1 * 64]) & 0xff;
+#if DR_PHASE_HOME
+        // the phase-only state goes home (the values in registers are dead from here to the next phase)
+        st[2 * 64] = color.x; st[3 * 64] = color.y; st[4 * 64] = color.z;
+        st[5 * 64] = __int_as_float(((px + 1) << 16) | py); st[6 * 64] = __int_as_float(pcode);
+        st[7 * 64] = __int_as_float(sample);
+        reinterpret_cast<unsigned short*>(st + 1 * 64)[1] = (unsigned short)frame;
+        asm volatile("" ::: "memory");
+        color = mk(0, 0, 0); px = -1; py = 0; pcode = 0; sample = 0; frame = 0;
+#endif
         if (fresh_ray) { ws.top = 0u; ws.sp = 0; ws.sb = 0; }
         inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);      // 1/direction and the folded test's margins are
         wr = wide_ray(path.rayo, inv, P.wide_pmax);                                        // recomputed for every lane rather than stashed
@@ -394,7 +421,11 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       const bool can_give = tr.node >= 0 && (ws.sp > ws.sb || ws.top != 0u) && (int)(steps - rstart) >= P.coop_steps;
       const unsigned long long givers = __ballot(can_give);
       const int n_idle = (int)__popcll(idle), n_give = (int)__popcll(givers);
-      const int n = n_idle < n_give ? n_idle : n_give;
+      // (with the phase-only state at home in stash words 1-7, the exchange has words 8-9 of the stash -- the step counts, in registers
+      // between phases -- to itself: 128 words = 16 hand-overs of 8 words per round)
+      constexpr int XCH_MAX = DR_PHASE_HOME ? 16 : 64;
+      const int n_most = n_idle < n_give ? n_idle : n_give;
+      const int n = n_most < XCH_MAX ? n_most : XCH_MAX;
       if (DR_WAVE_LOG_DETAIL && round == 0) {
         d_share_iters++; d_want_give += (unsigned long long)n_give; d_idle += (unsigned long long)n_idle;
         d_owner_walk += (unsigned long long)__popcll(__ballot(tr.node >= 0 && px >= 0));
@@ -404,7 +435,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (n == 0) break;
       {
         if (DR_WAVE_LOG_DETAIL) d_given += (unsigned long long)n;
-        int* const xch = my_lds + DR_LDS_STACK * 64;                 // the phase stash is free between phases: 8 words per hand-over
+        int* const xch = my_lds + (DR_LDS_STACK + (DR_PHASE_HOME ? 8 : 0)) * 64;      // field f of hand-over e at xch[f * XCH_MAX + e]
         const int rank_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(givers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)givers, 0u));
         const int rank_i = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
         if (can_give && rank_g < n) {
@@ -414,18 +445,18 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           unsigned word;
           if (ws.sp > ws.sb) { word = (unsigned)my_stack[ws.sb * 64]; ws.sb++; }
           else { word = ws.top; ws.top = 0u; }
-          xch[rank_g + 0 * 64] = __float_as_int(path.rayo.x); xch[rank_g + 1 * 64] = __float_as_int(path.rayo.y); xch[rank_g + 2 * 64] = __float_as_int(path.rayo.z);
-          xch[rank_g + 3 * 64] = __float_as_int(path.raydir.x); xch[rank_g + 4 * 64] = __float_as_int(path.raydir.y); xch[rank_g + 5 * 64] = __float_as_int(path.raydir.z);
-          xch[rank_g + 6 * 64] = (int)word; xch[rank_g + 7 * 64] = root;
+          xch[rank_g + 0 * XCH_MAX] = __float_as_int(path.rayo.x); xch[rank_g + 1 * XCH_MAX] = __float_as_int(path.rayo.y); xch[rank_g + 2 * XCH_MAX] = __float_as_int(path.rayo.z);
+          xch[rank_g + 3 * XCH_MAX] = __float_as_int(path.raydir.x); xch[rank_g + 4 * XCH_MAX] = __float_as_int(path.raydir.y); xch[rank_g + 5 * XCH_MAX] = __float_as_int(path.raydir.z);
+          xch[rank_g + 6 * XCH_MAX] = (int)word; xch[rank_g + 7 * XCH_MAX] = root;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (tr.node == -3 && rank_i < n) {
-          path.rayo = mk(__int_as_float(xch[rank_i + 0 * 64]), __int_as_float(xch[rank_i + 1 * 64]), __int_as_float(xch[rank_i + 2 * 64]));
-          path.raydir = mk(__int_as_float(xch[rank_i + 3 * 64]), __int_as_float(xch[rank_i + 4 * 64]), __int_as_float(xch[rank_i + 5 * 64]));
-          ws.top = (unsigned)xch[rank_i + 6 * 64]; ws.sp = 0; ws.sb = 0;
-          share = xch[rank_i + 7 * 64];
+          path.rayo = mk(__int_as_float(xch[rank_i + 0 * XCH_MAX]), __int_as_float(xch[rank_i + 1 * XCH_MAX]), __int_as_float(xch[rank_i + 2 * XCH_MAX]));
+          path.raydir = mk(__int_as_float(xch[rank_i + 3 * XCH_MAX]), __int_as_float(xch[rank_i + 4 * XCH_MAX]), __int_as_float(xch[rank_i + 5 * XCH_MAX]));
+          ws.top = (unsigned)xch[rank_i + 6 * XCH_MAX]; ws.sp = 0; ws.sb = 0;
+          share = xch[rank_i + 7 * XCH_MAX];
           inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
           wr = wide_ray(path.rayo, inv, P.wide_pmax);
           const unsigned long long k = share_key[share];

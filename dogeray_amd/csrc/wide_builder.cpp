@@ -13,7 +13,7 @@
 //      the reference's topology (option wide_tree = 0, for comparison);
 //   2. collapsed into nodes with up to four children (largest child opened first);
 //   3. laid out as 64-byte records, children of a node contiguous, child boxes quantised to 8 bits on a
-//      per-node grid {origin, power-of-two scale} and rounded OUTWARD; every decoded plane is checked here
+//      per-node grid {origin, power-of-two scale; the record stores scale * 2^24} and rounded OUTWARD; every decoded plane is checked here
 //      with the same fmaf the kernel uses, so enclosure is a verified fact, not an error estimate.
 //
 // Leaves keep the reference's exact box and {v0, e1, e2}; slot = rank of the leaf in the reference's
@@ -238,9 +238,9 @@ bool quantise(const Box* cb, int n, float origin[3], float scale[3], uint8_t lo[
     int e;
     (void)frexpf(ext > 0 ? ext / 255.0f : 0.0f, &e);       // ext / 255 = m * 2^e, m in [0.5, 1): 2^e >= ext / 255
     if (!(ext > 0)) e = -60;
-    if (e < -60) e = -60;                                   // scale in [2^-60, 2^60]: scale * (1 / direction) stays exact in the kernel
+    if (e < -60) e = -60;                                   // scale in [2^-60, 2^36]: scale * (1 / direction) * 2^24 stays exact in the kernel (wide_node_test)
     for (;; e++) {
-      if (e > 60) return false;
+      if (e > 36) return false;
       const float s = ldexpf(1.0f, e);
       bool ok = true;
       for (int k = 0; k < n && ok; k++) {
@@ -363,7 +363,7 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
     for (int a = 0; a < 3; a++) pmax = fmaxf(pmax, fmaxf(fabsf(origin[a]), fabsf(fmaf(255.0f, scale[a], origin[a]))));
     uint32_t words[WIDE_UNITS * 4];
     memset(words, 0, sizeof(words));
-    for (int a = 0; a < 3; a++) { words[a] = fbits(origin[a]); words[4 + a] = fbits(scale[a]); }
+    for (int a = 0; a < 3; a++) { words[a] = fbits(origin[a]); words[4 + a] = fbits(ldexpf(scale[a], 24)); }      // the record holds scale * 2^24 (device_core.hpp DR_NODE_V2)
     words[3] = 0x80000000u | (uint32_t)base;
     words[7] = ((1u << w.n) - 1u) | (leafmask << 4);
     for (int a = 0; a < 3; a++) {

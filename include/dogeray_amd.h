@@ -338,6 +338,10 @@ int dr_kat_optics(dr_context* c, int n, const float* v, const float* nrm, const 
  * the normalised, not yet flipped normal and the interpolated texture coordinate (z = 0), 3 floats each */
 int dr_kat_normal(dr_context* c, int n, const int32_t* object_index, const float* o, const float* d, const float* t,
                   float* normal, float* texco);
+/* The plane arithmetic of the wide walk's node test (device_core.hpp wide_node_test): for word w[i] (four plane bytes) t_mix[4 i + k] =
+ * fma(byte_k read as the f16 denormal byte * 2^-24 inside v_fma_mix_f32, a[i] * 2^24, b[i]) and t_cvt[4 i + k] = fma((float)byte_k, a[i], b[i]):
+ * the two must agree bit for bit (a[i] * 2^24 must not overflow) -- the check that the instruction keeps f16 denormals */
+int dr_kat_node_planes(dr_context* c, int n, const uint32_t* w, const float* a, const float* b, float* t_mix, float* t_cvt);
 /* closest hit against the resident scene: t (-1 = miss), ORIGINAL object index and (visits may be NULL)
  * the number of boxes the chosen traversal tested for that ray */
 int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, int32_t* idx, int32_t* visits);

@@ -86,6 +86,21 @@ def test_triangle(ctx, orc):
     assert 0.1 < (g > 0).mean() < 0.9
 
 
+def test_node_plane_arithmetic(ctx):
+    """wide_node_test reads a plane byte as the f16 denormal byte * 2^-24 inside v_fma_mix_f32 (one instruction per plane): the result must be
+    fma(byte, a, b) bit for bit -- i.e. the instruction keeps f16 denormals and rounds once -- over the whole range of a = scale / direction"""
+    rng = np.random.default_rng(11)
+    n = 200_000
+    w = rng.integers(0, 2**32, size=n, dtype=np.uint64).astype(np.uint32)
+    w[:4] = [0, 0xffffffff, 0x00ff00ff, 0xff00ff00]
+    a = (rng.uniform(0.5, 1, size=n) * np.exp2(rng.integers(-120, 97, size=n)) * rng.choice([-1, 1], size=n)).astype(np.float32)
+    b = (rng.normal(size=n) * np.exp2(rng.integers(-30, 40, size=n))).astype(np.float32)
+    b[::7] = 0
+    t_mix, t_cvt = ctx.kat_node_planes(w, a, b)
+    assert np.array_equal(bits(t_mix), bits(t_cvt))
+    assert np.isfinite(t_cvt).mean() > 0.99 and len(np.unique(t_cvt)) > n
+
+
 def test_sphere(ctx, orc):
     rng = np.random.default_rng(3)
     n = 100_000

@@ -1,7 +1,8 @@
 // Host emulation of the wide walk (device_core.hpp wide_* functions, same arithmetic and stack discipline) against the
 // threaded reference-order walk, on camera rays + two diffuse bounces: checks that hits are identical and prints visits per ray,
-// build time and tree statistics.  Build from the repo root:
-//   g++ -std=c++17 -O2 -ffp-contract=off -I dogeray_amd/csrc -I include -o /tmp/widewalk tools/study_wide_walk.cpp \
+// build time and tree statistics.  The folded node test is the kernel's own source (device_core.hpp compiled for the host, as in
+// tools/host_kernel.cpp), checked at every node against the plain decode-and-slab test it must cover.  Build from the repo root:
+//   /opt/rocm/lib/llvm/bin/clang++ -std=c++17 -O2 -ffp-contract=off -mfma -DDR_HOST_BUILD=1 -I tools/host_kernel -I dogeray_amd/csrc -I include -o /tmp/widewalk tools/study_wide_walk.cpp \
 //       dogeray_amd/csrc/linearise.cpp dogeray_amd/csrc/wide_builder.cpp dogeray_amd/csrc/rts_reader.cpp \
 //       dogeray_amd/csrc/bvh_builder.cpp dogeray_amd/csrc/capi_host.cpp -pthread && /tmp/widewalk scene.rts 20000 [tree_mode]
 #include <algorithm>
@@ -13,6 +14,7 @@
 #include <random>
 
 #include "linearise.hpp"
+#include "device_core.hpp"
 using namespace dr;
 
 static bool slab(const float o[3], const float inv[3], const float mn[3], const float mx[3], float& dist) {
@@ -34,9 +36,8 @@ static float tri(const float o[3], const float d[3], const float* v0, const floa
 struct WideStats { long nodes = 0, leaves = 0, tests = 0, maxsp = 0, cull_nodes = 0, cull_leaves = 0, cull_entry = 0, extra_children = 0, leafkids[5] = {0, 0, 0, 0, 0}; };
 
 static void wide_hit(const std::vector<DevUnit>& rec, float pmax, const float o[3], const float d[3], const float inv[3], float& best_t, int& best_slot, WideStats& ws) {
-  best_t = 1e7f; best_slot = -1;
-  float marg[3], invc[3];   // wide_ray(): clamped 1/direction and margins of the folded test
-  for (int a = 0; a < 3; a++) { invc[a] = fminf(fmaxf(inv[a], -0x1p60f), 0x1p60f); const float k = fmaf(pmax + fabsf(o[a]), 0x1p-21f, 0x1p-40f), ai = fabsf(invc[a]); marg[a] = (inv[a] == inv[a] && ai > 0x1p-60f) ? ai * k : NAN; }
+  best_t = 10000.0f; best_slot = -1;      // trav_begin
+  const WideRay wr = wide_ray(mk(o[0], o[1], o[2]), mk(inv[0], inv[1], inv[2]), pmax);
   unsigned stack[WIDE_STACK]; int sp = 0; unsigned top = 0;
   float sd[WIDE_STACK + 1][4]; float topd[4] = {0, 0, 0, 0};   // study only: entry distance of every pending child
   unsigned cur = 0;   // index << 1 | leaf
@@ -59,25 +60,26 @@ static void wide_hit(const std::vector<DevUnit>& rec, float pmax, const float o[
       ws.nodes++;
       const unsigned base = w[3] & 0xffffffu, valid = w[7] & 15u, leafmask = (w[7] >> 4) & 15u;
       // the kernel's folded test (wide_node_test, DR_WIDE_FOLD) and, as a check, the plain decode-and-slab test it must cover
-      unsigned mask = 0, mask_plain = 0, key = 0xffffffffu; float dist[4] = {0, 0, 0, 0};
-      const float tcap = fminf(best_t, 10000.0f);
-      float a3[3], bn[3], bf[3];
-      for (int a = 0; a < 3; a++) { a3[a] = f[4 + a] * invc[a]; const float b = (f[a] - o[a]) * invc[a]; bn[a] = b - marg[a]; bf[a] = b + marg[a]; }
+      unsigned mask_plain = 0, key = 0xffffffffu; float dist[4] = {0, 0, 0, 0};
+      u32x4 RA, RB, RC, RD; memcpy(&RA, w, 16); memcpy(&RB, w + 4, 16); memcpy(&RC, w + 8, 16); memcpy(&RD, w + 12, 16);
+      unsigned mask = wide_node_test(RA, RB, RC, RD, mk(o[0], o[1], o[2]), mk(inv[0], inv[1], inv[2]), wr, best_t, key);      // the kernel's test
+      float nearest_plain = INFINITY;
       for (int k = 0; k < 4; k++) {
-        float mn[3], mx[3], t0[3], t1[3];
+        float mn[3], mx[3];
         for (int a = 0; a < 3; a++) {
           const float ql = (float)((w[8 + a] >> (8 * k)) & 255u), qh = (float)((w[11 + a] >> (8 * k)) & 255u);
-          mn[a] = fmaf(ql, f[4 + a], f[a]); mx[a] = fmaf(qh, f[4 + a], f[a]);
-          const float qn = inv[a] < 0 ? qh : ql, qf = inv[a] < 0 ? ql : qh;
-          t0[a] = fmaf(qn, a3[a], bn[a]); t1[a] = fmaf(qf, a3[a], bf[a]);
+          const float sc = f[4 + a] * 0x1p-24f;      // the record holds scale * 2^24
+          mn[a] = fmaf(ql, sc, f[a]); mx[a] = fmaf(qh, sc, f[a]);
         }
         float dplain;
-        if (slab(o, inv, mn, mx, dplain) && dplain <= best_t) mask_plain |= 1u << k;
-        const float tmin = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), t0[2]), 0.0f), tmax = fminf(fminf(fminf(t1[0], t1[1]), t1[2]), tcap);
-        if (tmax >= tmin) { mask |= 1u << k; uint32_t kb; memcpy(&kb, &tmin, 4); kb = (kb & ~3u) | (unsigned)k; if (kb < key) key = kb; if (dplain < tmin && (mask_plain >> k & 1)) { printf("folded entry distance later than the plain one: %g > %g\n", tmin, dplain); exit(3); } }
-        dist[k] = tmin;
+        if (slab(o, inv, mn, mx, dplain) && dplain <= best_t) { mask_plain |= 1u << k; if ((valid >> k) & 1u) nearest_plain = fminf(nearest_plain, dplain); }
+        dist[k] = dplain;      // (study only: the culling statistics below)
       }
-      mask &= valid; mask_plain &= valid;
+      if ((mask_plain & valid) && (mask & valid)) {      // the nearest key's entry distance may not be later than the nearest plain one
+        const uint32_t kb = key & ~3u; float kt; memcpy(&kt, &kb, 4);
+        if (kt > nearest_plain) { printf("folded entry distance later than the plain one: %g > %g\n", kt, nearest_plain); exit(3); }
+      }
+      mask_plain &= valid;
       if (mask_plain & ~mask) { printf("FOLDED TEST NOT CONSERVATIVE: plain %x folded %x\n", mask_plain, mask); exit(3); }
       ws.extra_children += __builtin_popcount(mask & ~mask_plain);
       if (leafmask & valid) ws.leafkids[__builtin_popcount(mask & leafmask)]++;
