@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 #ifndef DR_PHASE_HOME
 #define DR_PHASE_HOME (!DR_WAVE_LOG_DETAIL)           // wide walk: colour, pixel, sample and frame live in the phase stash outside the phase (0: in registers, as before)
 #endif
+#ifndef DR_SIGN_MASKS
+#define DR_SIGN_MASKS 1           // wide walk: near / far planes selected with per-lane sign words and v_bitop3 (device_core.hpp SignMask; 0: compare + v_cndmask per step)
+#endif
 #ifndef DR_EXCLUSIVE_STEPS
 #define DR_EXCLUSIVE_STEPS 1      // wide walk: an iteration's step is a leaf step OR a node step (0: both kinds of lanes step together, as in round 2)
 #endif
@@ -140,6 +143,11 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
   V3 inv = mk(0, 0, 0), color = mk(0, 0, 0);
   WideRay wr = wide_ray_none();    // WIDE: clamped 1/direction and margins of the folded node test, a function of the lane's ray
+#if DR_SIGN_MASKS
+  SignMask sg = sign_mask(inv);    // ... and the signs of 1/direction as select masks
+#else
+  SignCmp sg; sg.inv = inv;
+#endif
   Xorwow rng; rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = rng.d = 0;
   int px = -1, py = 0, sample = 0, bounce = 0;
   int frame = 0;                   // frame of the batch the pixel in this slot belongs to
@@ -204,6 +212,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked) && !waits_for_helpers;
       if (COUNT) n_shaded += __popcll(__ballot(shade_me));
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
+      constexpr bool BOUNCE_HOME = WIDE && !COOP && DR_PHASE_HOME;      // lean build: the bounce count lives in stash word 9 (one register more for the walk)
       float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? DR_LDS_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
       if (WIDE) {
         // ten words (26 KiB of LDS per workgroup with the stack: six workgroups per CU).  Words 2-7 (colour, x + 1 (0: no pixel) with y -- make_params
@@ -219,7 +228,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         st[5 * 64] = __int_as_float(((px + 1) << 16) | py); st[6 * 64] = __int_as_float(pcode);
         st[7 * 64] = __int_as_float(sample);
 #endif
-        st[8 * 64] = __uint_as_float(steps); st[9 * 64] = __uint_as_float(rstart);
+        st[8 * 64] = __uint_as_float(steps);
+        if (COOP || !DR_PHASE_HOME) st[9 * 64] = __uint_as_float(rstart);      // (lean build: the ray's first step is of no use to it, and word 9 is where `bounce` lives)
         asm volatile("" ::: "memory");
       } else {
         st[0 * 64] = pk.v0x; st[1 * 64] = __uint_as_float(pk.C.x); st[2 * 64] = __uint_as_float(pk.C.y); st[3 * 64] = __uint_as_float(pk.C.z); st[4 * 64] = __uint_as_float(pk.C.w);
@@ -241,8 +251,10 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         if (tr.best_slot >= 0 && tr.best_t > 0.0f) {
           ended = !shade_hit<COUNT>(P, path, tr.best_t, tr.best_slot, rng, c, radiance);
           if (!ended) {
+            if (BOUNCE_HOME) bounce = __float_as_int(st[9 * 64]);
             bounce++;
             if (bounce >= P.max_depth) ended = true;        // depth exhausted: black (K:981)
+            if (BOUNCE_HOME) st[9 * 64] = __int_as_float(bounce);
           }
         } else {
           radiance = shade_miss<COUNT>(P, path, c);
@@ -256,7 +268,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         { const int xy = __float_as_int(st[5 * 64]); px = (int)((unsigned)xy >> 16) - 1; py = xy & 0xffff; }
         pcode = __float_as_int(st[6 * 64]);
         frame = (int)((unsigned)__float_as_int(st[1 * 64]) >> 16); sample = __float_as_int(st[7 * 64]);
-        steps = __float_as_uint(st[8 * 64]); rstart = __float_as_uint(st[9 * 64]);
+        steps = __float_as_uint(st[8 * 64]);
+        if (COOP || !DR_PHASE_HOME) rstart = __float_as_uint(st[9 * 64]);
       } else {
         asm volatile("" ::: "memory");
         color = mk(st[14 * 64], st[15 * 64], st[16 * 64]);
@@ -374,6 +387,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           camera_ray(P, px, py, rng, path.rayo, path.raydir);
           path.atten = splat(1.0f);
           bounce = 0;
+          if (BOUNCE_HOME) st[9 * 64] = __int_as_float(0);
           trav_begin(tr);
           rstart = steps;
           fresh_ray = true;
@@ -395,6 +409,11 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         if (fresh_ray) { ws.top = 0u; ws.sp = 0; ws.sb = 0; }
         inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);      // 1/direction and the folded test's margins are
         wr = wide_ray(path.rayo, inv, P.wide_pmax);                                        // recomputed for every lane rather than stashed
+#if DR_SIGN_MASKS
+        sg = sign_mask(inv);
+#else
+        sg.inv = inv;
+#endif
       } else {
         asm volatile("" ::: "memory");
         pk.v0x = st[0 * 64]; pk.C = u32x4{__float_as_uint(st[1 * 64]), __float_as_uint(st[2 * 64]), __float_as_uint(st[3 * 64]), __float_as_uint(st[4 * 64])};
@@ -459,6 +478,11 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           share = xch[rank_i + 7 * XCH_MAX];
           inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
           wr = wide_ray(path.rayo, inv, P.wide_pmax);
+#if DR_SIGN_MASKS
+          sg = sign_mask(inv);
+#else
+          sg.inv = inv;
+#endif
           const unsigned long long k = share_key[share];
           tr.best_t = __uint_as_float((unsigned)(k >> 32)); tr.best_slot = (int)(unsigned)k;
           wide_pop(tr, ws, my_stack);                              // the first pending child of the word
@@ -525,8 +549,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (tr.node >= 0 && (at_leaf ? do_leaves : do_nodes)) {
         if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
         const WideRec r = wide_fetch(walk, tr.node);
-        if (at_leaf) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, tr, ws, my_stack, c);
-        else wide_node_compute<COUNT>(r, path.rayo, inv, wr, tr, ws, my_stack, c);
+        if (at_leaf) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, sg, tr, ws, my_stack, c);
+        else wide_node_compute<COUNT>(r, path.rayo, inv, wr, sg, tr, ws, my_stack, c);
         steps++;
       }
 #if DR_MERGED_STEPS
@@ -544,8 +568,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         if (tr.node >= 0 && (at_leaf2 ? do_leaves2 : do_nodes2)) {
           if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
           const WideRec r = wide_fetch(walk, tr.node);
-          if (at_leaf2) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, tr, ws, my_stack, c);
-          else wide_node_compute<COUNT>(r, path.rayo, inv, wr, tr, ws, my_stack, c);
+          if (at_leaf2) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, sg, tr, ws, my_stack, c);
+          else wide_node_compute<COUNT>(r, path.rayo, inv, wr, sg, tr, ws, my_stack, c);
           steps++;
         }
       }
