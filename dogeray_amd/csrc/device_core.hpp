@@ -69,6 +69,16 @@ __device__ __forceinline__ int f2i(float f) {
 
 // ------------------------------------------------------------------ RNG: cuRAND XORWOW
 // curand_init(seed, 0, 0) / curand() / curand_uniform_double() (call sites K:644,657,1065-1068)
+__device__ __forceinline__ double bits_double(uint32_t hi, uint32_t lo) {      // the double with these two words
+#ifndef DR_HOST_BUILD
+  // (the high word is a constant: set where it is used -- hoisted out of the kernel's main loop, the two constants of Xorwow::z_plus_half would
+  // occupy two registers through every node and leaf step, where there are none to spare)
+  asm volatile("v_mov_b32 %0, %1" : "=v"(hi) : "s"(hi));
+#endif
+  const uint64_t b = ((uint64_t)hi << 32) | lo;
+  double r; __builtin_memcpy(&r, &b, 8);
+  return r;
+}
 struct Xorwow {
   uint32_t v0, v1, v2, v3, v4, d;
   __device__ __forceinline__ void init(uint64_t seed) {
@@ -90,21 +100,66 @@ struct Xorwow {
     d += 362437u;
     return v4 + d;
   }
+  // curand_uniform_double(): z = x ^ (y << 21) (53 bits), (double)z * 2^-53 + 2^-54.  The conversion and the arithmetic behind it are restated
+  // with fewer operations and THE SAME roundings (tools/host_kernel.cpp hk_check_uniform compares them with the plain expressions):
+  //  * (double)z = ((2^84 + hi * 2^32) - (2^84 + 2^52)) + (2^52 + lo), hi = z >> 32, lo = the low word: both terms are doubles whose high word is a
+  //    constant and whose low word is hi / lo, and both additions are exact -- two f64 adds instead of two conversions, a scaling and an add
+  //    (and no 64-bit shift);
+  //  * RN(z * 2^-53 + 2^-54) = RN(z + 0.5) * 2^-53 (a power of two commutes with the rounding);
+  //  * (float)(u * 2 - 1) of the unit-sphere draw = (float)fma(RN(z + 0.5), 2^-52, -1): u * 2 is exact, so the subtraction's rounding is the fma's.
+  __device__ __forceinline__ double z_plus_half() {               // RN((double)z + 0.5)
+    const uint32_t x = next(), y = next();
+    const uint32_t lo = x ^ (y << 21), hi = y >> 11;
+    const double d_hi = bits_double(0x45300000u, hi), d_lo = bits_double(0x43300000u, lo);
+    return ((d_hi - 19342813118337666422669312.0) + d_lo) + 0.5;
+  }
+#ifndef DR_UNIFORM_V2
+#define DR_UNIFORM_V2 1      // 0: the plain expressions (A/B builds)
+#endif
+#if DR_UNIFORM_V2
+  __device__ __forceinline__ double uniform_double() { return z_plus_half() * 0x1p-53; }
+  __device__ __forceinline__ float uniform_pm1() { return (float)__builtin_fma(z_plus_half(), 0x1p-52, -1.0); }      // (float)(uniform_double() * 2 - 1)
+#else
   __device__ __forceinline__ double uniform_double() {
     uint32_t x = next(), y = next();
     uint64_t z = (uint64_t)x ^ ((uint64_t)y << 21);
     return (double)z * 1.1102230246251565e-16 + 5.5511151231257827e-17;
   }
+  __device__ __forceinline__ float uniform_pm1() { return (float)(uniform_double() * 2 - 1); }
+#endif
 };
 
+// The rejection test of K:645 / K:992 is pow(length(p), 2.0f) >= 1 with length = sqrtf(dot): l = RN(sqrt(d2)), then RN(l * l) >= 1.  Away from 1 the
+// outcome is that of d2 >= 1 itself: for d2 <= 1 - 2^-20, sqrt(d2) <= 1 - 2^-21 (a float), so l <= 1 - 2^-21 and l * l <= 1 - 2^-20 + 2^-42 rounds
+// below 1; for d2 >= 1 + 2^-20, sqrt(d2) >= 1 + 2^-21 - 2^-43 rounds to at least 1 + 2^-21 and l * l > 1.  Only inside that band is the correctly
+// rounded square root (some fifteen instructions) really taken -- and the wave branches around it when none of its lanes is in the band.
+__device__ __forceinline__ bool outside_unit(float d2) {
+#if !DR_UNIFORM_V2
+  { const float l = __builtin_sqrtf(d2); return l * l >= 1; }
+#endif
+  const bool band = __builtin_fabsf(d2 - 1.0f) < 0x1p-20f;
+  bool out = d2 >= 1;
+#ifndef DR_HOST_BUILD
+  if (__builtin_amdgcn_ballot_w64(band) != 0ull)                  // (wave-uniform)
+#endif
+  {
+#ifndef DR_HOST_BUILD
+    asm volatile("; rare: a lane within 2^-20 of the unit sphere");      // (keeps the compiler from hoisting the square root out of the branch)
+#endif
+    if (band) {
+      const float l = __builtin_sqrtf(d2);
+      out = l * l >= 1;                                           // pow(len, 2.0f)
+    }
+  }
+  return out;
+}
 __device__ __forceinline__ V3 rand_in_unit_sphere(Xorwow& r) {   // K:640-648
   for (;;) {
-    float x = (float)(r.uniform_double() * 2 - 1);
-    float y = (float)(r.uniform_double() * 2 - 1);
-    float z = (float)(r.uniform_double() * 2 - 1);
+    float x = r.uniform_pm1();
+    float y = r.uniform_pm1();
+    float z = r.uniform_pm1();
     V3 p = mk(x, y, z);
-    float l = length(p);
-    if (l * l >= 1) continue;                                     // pow(len, 2.0f)
+    if (outside_unit(dot(p, p))) continue;
     return p;
   }
 }
@@ -114,8 +169,7 @@ __device__ __forceinline__ V3 rand_in_unit_disk(Xorwow& r) {     // K:988-994
     float x = randy(r) * 2 - 1;
     float y = randy(r) * 2 - 1;
     V3 p = mk(x, y, 0);
-    float l = length(p);
-    if (l * l >= 1) continue;
+    if (outside_unit(dot(p, p))) continue;
     return p;
   }
 }

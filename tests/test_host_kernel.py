@@ -60,6 +60,13 @@ def test_host_build_of_the_kernel_renders_like_the_oracle(hk, orc, synth, tmp_pa
             assert gc["V"] == wc["V"] and gc["L"] == wc["L"]
 
 
+def test_restated_uniform_draws_round_like_the_plain_expressions(hk):
+    """device_core.hpp computes curand_uniform_double(), (float)(u * 2 - 1) and the unit-sphere rejection test with fewer operations; every one of
+    them must round exactly as the plain expression does: 20 million generator outputs, the corners of the 53-bit integer, every float within 2^-18
+    of 1 for the rejection test"""
+    assert hk.lib().hk_check_uniform(20_000_000, 12345) == 0
+
+
 def test_host_build_stripes_and_thread_counts_do_not_change_pixels(hk, orc, synth):
     path = os.path.join(synth["dir"], "city_small.rts")
     a = orc.Scene(path)

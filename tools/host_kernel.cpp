@@ -8,6 +8,8 @@
 // kernel's arithmetic that needs no GPU) and bench.py reports it as cpu_baseline.kind "same-source" beside the oracle's "port".
 // It is not linked into libdogeray_amd.so, which has no CPU path (dr_context_create fails without a GPU).
 #include <atomic>
+#include <cmath>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -54,6 +56,37 @@ void render_columns(const RenderParams& P, int traversal, int first, int step, C
 }  // namespace
 
 extern "C" {
+
+// The restated uniform draws of device_core.hpp (Xorwow::uniform_double, uniform_pm1, outside_unit) against the plain expressions of
+// curand_uniform_double (CUDA 11.2 curand_kernel.h) and of kernel.cu K:640-648: n random generator outputs plus the corners; returns mismatches.
+long long hk_check_uniform(long long n, unsigned long long seed) {
+  long long bad = 0;
+  auto one = [&bad](uint32_t x, uint32_t y) {
+    const uint64_t z = (uint64_t)x ^ ((uint64_t)y << 21);
+    const volatile double u_plain = (double)z * 1.1102230246251565e-16 + 5.5511151231257827e-17;
+    const volatile double t = u_plain * 2;
+    const float f_plain = (float)(t - 1);
+    const uint32_t lo = x ^ (y << 21), hi = y >> 11;
+    const double zh = ((bits_double(0x45300000u, hi) - 19342813118337666422669312.0) + bits_double(0x43300000u, lo)) + 0.5;
+    const double u_new = zh * 0x1p-53;
+    const float f_new = (float)__builtin_fma(zh, 0x1p-52, -1.0);
+    if (memcmp((const void*)&u_plain, &u_new, 8) != 0 || memcmp(&f_plain, &f_new, 4) != 0) bad++;
+  };
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto rnd = [&s]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  for (long long i = 0; i < n; i++) { const uint64_t r = rnd(); one((uint32_t)r, (uint32_t)(r >> 32)); }
+  const uint32_t corners[] = {0u, 1u, 2u, 3u, 0x7ffu, 0x800u, 0x801u, 0x3ffu, 0x400u, 0x401u, 0x7fffffffu, 0x80000000u, 0x80000001u, 0xfffffffeu, 0xffffffffu, 0x001fffffu, 0x00200000u, 0xffe00000u, 0xffdfffffu};
+  for (uint32_t a : corners) for (uint32_t b : corners) one(a, b);
+  // the rejection test: floats around 1 (every float within 2^-18 of 1) and a sweep
+  auto test = [&bad](float d2) {
+    const volatile float l = sqrtf(d2);
+    const bool plain = l * l >= 1;
+    if (plain != outside_unit(d2)) bad++;
+  };
+  for (int k = -(1 << 18); k <= (1 << 18); k++) { uint32_t b = 0x3f800000u + (uint32_t)k; float f; memcpy(&f, &b, 4); test(f); }
+  for (long long i = 0; i < n / 4; i++) { const uint64_t r = rnd(); test((float)(r >> 40) * (3.0f / 16777216.0f)); }
+  return bad;
+}
 
 const char* hk_last_error() { return hk_err.c_str(); }
 

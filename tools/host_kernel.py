@@ -37,6 +37,8 @@ def lib():
         L.hk_scene_load.argtypes = [C.c_char_p, C.c_char_p]
         L.hk_scene_free.argtypes = [C.c_void_p]
         L.hk_has_wide.argtypes = [C.c_void_p]
+        L.hk_check_uniform.restype = C.c_longlong
+        L.hk_check_uniform.argtypes = [C.c_longlong, C.c_ulonglong]
         L.hk_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
