@@ -571,9 +571,17 @@ def main():
         rf["achieved"] = lane_ops / 1e12
         rf["frac"] = lane_ops / VALU_PEAK_LANE_OPS
         rf["traffic"] = t["bytes_per_launch"]
+        # `frac` does not rise when work is removed (fewer instructions per ray lower lane_ops and launch_ms together).  For a number that moves with
+        # the rate: the rays per second of this run times the active-lane operations ROUND 2's kernel spent per ray (159.8 wave-level instructions
+        # x 64 lanes x 0.359 lane use, profiles/r2_b), over the same peak -- 0.245 in round 2 (C4 only: the constant is that scene's)
+        if args.config == "C4":
+            rf["frac_at_round2_work"] = (rays / frames * frames_per_launch) / (launch_ms * 1e-3) * (159.8 * 64 * 0.359) / VALU_PEAK_LANE_OPS
         rf["valu"] = {"wave_instructions_per_launch": t["SQ_INSTS_VALU"], "active_lane_ops_per_launch": t["SQ_THREAD_CYCLES_VALU"],
                       "lane_use": t["SQ_THREAD_CYCLES_VALU"] / (64.0 * t["SQ_INSTS_VALU"]),
                       "issue_busy_frac_at_2_cycles_per_instruction": t["SQ_INSTS_VALU"] * 2.0 / (1024 * 2.4e9 * launch_ms * 1e-3),
+                      "issue_cost_note": "measured issue cost per wave-level instruction at six waves per SIMD (tools/valu_rate.hip, profiles/r3_l_*): 2.4 cycles "
+                                         "(fma / mul / add f32, and / or / xor / bitop3, add u32, mov), 4.2 (min / max, compares, cndmask, conversions, shifts, "
+                                         "fma_mix, perm, every f64 operation), 8.2 (rcp, sqrt); the classes overlap partly",
                       "wave_instructions_per_ray": t["SQ_INSTS_VALU"] / (rays / frames * frames_per_launch),
                       "salu_per_launch": t["SQ_INSTS_SALU"], "vmem_rd_per_launch": t["SQ_INSTS_VMEM_RD"]}
         hbm_gbs = t["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9

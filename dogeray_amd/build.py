@@ -48,7 +48,9 @@ def build(force=False, verbose=False):
             # -enable-post-misched=0: without the post-register-allocation machine scheduler the persistent kernel is 1.1 % faster
             # (0.6176 against 0.6244 ms/frame, three interleaved runs on two boxes; same registers, no spills); max-ilp / iterative-ilp /
             # max-memory-clause scheduling strategies: -0.4 % / +2.6 % / 0
-            sched = ["-mllvm", "-enable-post-misched=0"]
+            # -amdgpu-use-amdgpu-trackers=1 (the scheduler tracks register pressure with the target's own trackers): another 1.0 % on round 3's
+            # kernel (0.5670 against 0.5733 ms/frame, profiles/r3_p_*; same 80 VGPRs, no spills); relaxed occupancy / no high-pressure reschedule: +-0
+            sched = ["-mllvm", "-enable-post-misched=0", "-mllvm", "-amdgpu-use-amdgpu-trackers=1"]
             cmd = [hipcc] + COMMON + slp + sched + ["--offload-arch=" + ARCH, "-c", sp, "-o", obj]
             if src.endswith(".cpp"):
                 cmd = [hipcc] + COMMON + ["-x", "c++", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-c", sp, "-o", obj]

@@ -72,3 +72,17 @@ def random_scene(rng, n, path, W=96, H=64, textures=(), spheres=True, duplicates
     with open(path, "w") as f:
         f.write("\n".join(lines) + "\n")
     return path
+
+
+def stadium_scene(path, n=64, ratio=1.5, W=96, H=64):
+    """n triangles whose size and distance grow geometrically: the surface-area heuristic peels them off one or two at a time, so the wide tree reaches the
+    deepest shape the builder allows (wide_depth == WIDE_MAX_DEPTH = 17 for n = 64, ratio = 1.5 and for n = 200, ratio = 1.1: every word of the
+    kernel's per-lane stack is used).  The camera looks along the row, through all of them."""
+    with open(path, "w") as f:
+        f.write("*,-3.0,-1.0,0.5,0.01,%f,0,0,10,45,4,1,1,no,%d,%d\n" % (ratio ** (n - 1), W, H))
+        for i in range(n):
+            x = ratio ** i
+            s = 0.5 * x
+            mat = (0, 3, 5, 2)[i % 4]
+            f.write("%f,%f,%f,2,0.8,0.7,0.6,0.3,0,%f,%f,%f,%d,%f,%f,%f\n" % (x, -s, -s, x, s, -s, mat, x, 0, s))
+    return path

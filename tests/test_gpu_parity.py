@@ -229,6 +229,20 @@ def test_scene_frames(dr, orc, ctx, synth, mode, kernel):
                 print("   records visited: traversal %d: %d vs reference order %d; primitive tests %d vs %d" % (mode, stats["node_visits"], rc["V"], stats["prim_tests"], rc["L"]))
 
 
+@pytest.mark.parametrize("n,ratio", [(64, 1.5), (200, 1.1)])
+def test_deepest_wide_tree(dr, orc, ctx, tmp_path, n, ratio):
+    """a wide tree of exactly WIDE_MAX_DEPTH = 17 levels -- the per-lane LDS stack full to its last word -- through the persistent kernel (lean and
+    work-sharing build) and the tile kernel, against the oracle"""
+    from scene_fuzz import stadium_scene
+    path = stadium_scene(str(tmp_path / "stadium.rts"), n, ratio, W=192, H=128)
+    for kernel in (1, 0):
+        for seed in (5, 1 + 1000003 * 3):
+            g, r, stats, rc = _render_pair(dr, orc, ctx, path, "", 192, 128, 1, seed, mode=2, kernel=kernel)
+            assert ctx.get_option("traversal") == 2 and ctx.get_option("wide_depth") == 17
+            _assert_frames(g, r, "stadium %d x %.1f kernel %d" % (n, ratio, kernel))
+            assert stats["rays"] == rc["rays"] and stats["shades"] == rc["S"]
+
+
 @pytest.mark.parametrize("kernel,mode", [(0, 0), (1, 0), (1, 2)])
 def test_spp_and_aperture(dr, orc, ctx, synth, tmp_path, kernel, mode):
     """spp > 1 inside one launch (per-sample reseed, K:1059-1065) and a wide lens (K:1071-1073)."""

@@ -60,6 +60,19 @@ def test_host_build_of_the_kernel_renders_like_the_oracle(hk, orc, synth, tmp_pa
             assert gc["V"] == wc["V"] and gc["L"] == wc["L"]
 
 
+@pytest.mark.parametrize("n,ratio", [(64, 1.5), (200, 1.1)])
+def test_deepest_wide_tree_renders_like_the_oracle(hk, orc, tmp_path, n, ratio):
+    """a tree of exactly WIDE_MAX_DEPTH levels (the kernel's per-lane stack full to its last word) against the oracle and the threaded walk"""
+    from scene_fuzz import stadium_scene
+    path = stadium_scene(str(tmp_path / "stadium.rts"), n, ratio)
+    sc = hk.Scene(path, "")
+    assert sc.has_wide and sc.wide_depth() == 17
+    for traversal in (2, 0):
+        got, gc, want, wc = _both(hk, orc, path, "", 96, 64, 1, 99, traversal)
+        assert np.array_equal(got, want) and gc["rays"] == wc["rays"] and gc["S"] == wc["S"]
+        assert gc["rays"] > 96 * 64      # some paths bounce between the triangles
+
+
 def test_restated_uniform_draws_round_like_the_plain_expressions(hk):
     """device_core.hpp computes curand_uniform_double(), (float)(u * 2 - 1) and the unit-sphere rejection test with fewer operations; every one of
     them must round exactly as the plain expression does: 20 million generator outputs, the corners of the 53-bit integer, every float within 2^-18

@@ -117,6 +117,7 @@ void hk_scene_free(void* hv) {
 }
 
 int hk_has_wide(void* hv) { return ((HkScene*)hv)->img.wide.empty() ? 0 : 1; }
+int hk_wide_depth(void* hv) { return ((HkScene*)hv)->img.wide.empty() ? 0 : ((HkScene*)hv)->img.wide_depth; }      // nodes on the longest root-to-leaf path of the wide tree
 
 // One frame (dr_render_frame's arguments): int32[W * H * 3], pixel (x, y) at (x * H + y) * 3, unrendered margins 0; only the block
 // columns bx % col_mod == col_rem are rendered (a bounded sample for the bench).  counters: rays, V, L, S, T, samples (6 words).

@@ -37,6 +37,7 @@ def lib():
         L.hk_scene_load.argtypes = [C.c_char_p, C.c_char_p]
         L.hk_scene_free.argtypes = [C.c_void_p]
         L.hk_has_wide.argtypes = [C.c_void_p]
+        L.hk_wide_depth.argtypes = [C.c_void_p]
         L.hk_check_uniform.restype = C.c_longlong
         L.hk_check_uniform.argtypes = [C.c_longlong, C.c_ulonglong]
         L.hk_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
@@ -61,6 +62,9 @@ class Scene:
     @property
     def has_wide(self):
         return bool(lib().hk_has_wide(self.h))
+
+    def wide_depth(self):
+        return int(lib().hk_wide_depth(self.h))
 
     def render(self, settings13, W, H, background, frame_seed, traversal=2, nthreads=1, col_mod=1, col_rem=0, count=True):
         """One frame: (int32[W, H, 3] indexed [x, y], counters dict or None)."""

@@ -14,7 +14,7 @@ LANES = {"node": 30, "leaf": 23, "phase": 37}
 
 def main():
     d = tempfile.mkdtemp(prefix="dr_isa_")
-    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-enable-post-misched=0",
+    cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fno-slp-vectorize", "-mllvm", "-enable-post-misched=0", "-mllvm", "-amdgpu-use-amdgpu-trackers=1",
            "-DDR_ISA_MARKS=1", "--offload-arch=gfx950", "-c", os.path.join(ROOT, "dogeray_amd", "csrc", "kernels_render.hip"), "-o", os.path.join(d, "r.o"), "-save-temps"]
     subprocess.check_call(cmd, cwd=d, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     text = open(os.path.join(d, "kernels_render-hip-amdgcn-amd-amdhsa-gfx950.s")).read()

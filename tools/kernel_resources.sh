@@ -4,7 +4,7 @@
 R=$(cd "$(dirname "$0")/.." && pwd)
 U=${1:-kernels_render}
 rm -rf /tmp/kres && mkdir -p /tmp/kres && cd /tmp/kres
-/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=0 $3 --offload-arch=gfx950 -c $R/dogeray_amd/csrc/$U.hip -o u.o -save-temps 2>/dev/null
+/opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -enable-post-misched=0 -mllvm -amdgpu-use-amdgpu-trackers=1 $3 --offload-arch=gfx950 -c $R/dogeray_amd/csrc/$U.hip -o u.o -save-temps 2>/dev/null
 python3 - "$2" "$U" <<'PY'
 import re, sys
 t = open('/tmp/kres/%s-hip-amdgcn-amd-amdhsa-gfx950.s' % sys.argv[2]).read()

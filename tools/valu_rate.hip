@@ -127,6 +127,14 @@ KERNEL(floor_f32, F8(I_FLOOR))
 KERNEL(cvt_f32_fp8, F8(I_CVTPKFP8))
 KERNEL(fma_mix_all_f32, F8(I_MADMIX))
 KERNEL(cmp_nop_cndmask, F8(I_CMPCND))
+// mixes: do the two classes share one issue slot, or run side by side?  (x = 0..7: even registers get the first instruction, odd the second)
+#define M8(I0, I1) asm volatile(I0(0) I1(1) I0(2) I1(3) I0(4) I1(5) I0(6) I1(7) : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(b), "v"(c) : "vcc", "s4", "s5", "s6", "s7");
+KERNEL(mix_fma_max3, M8(I_FMA, I_MAX3))
+KERNEL(mix_fma_fmamix, M8(I_FMA, I_MIX))
+KERNEL(mix_or_cmp, M8(I_OR, I_CMP))
+KERNEL(mix_max3_perm, M8(I_MAX3, I_PERM))
+KERNEL(mix_fma_rcp, M8(I_FMA, I_RCP))
+KERNEL(mix_max3_rcp, M8(I_MAX3, I_RCP))
 // f64: four independent accumulators, two instructions each = 8 per block
 #define D8(INS) asm volatile(INS(0) INS(1) INS(2) INS(3) INS(0) INS(1) INS(2) INS(3) : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(e));
 #define I_FMA64(x) "v_fma_f64 %" #x ", %" #x ", %4, %4\n"
@@ -160,7 +168,8 @@ int main(int argc, char** argv) {
                            E(mov_b32), E(bitop3_b32), E(lshl_add_u32), E(cvt_f32_u32), E(s_nop_0), E(s_nop_1), E(fma_f64), E(mul_f64), E(add_f64), E(pk_fma_f32), E(cvt_f64_u32), E(cvt_f32_f64),
                            E(and_b32), E(add_f32), E(sub_f32), E(max_f32), E(min3_f32), E(med3_f32), E(fmac_f32), E(cndmask_sgpr), E(or_b32_sdwa_byte1), E(lshrrev_b32), E(alignbit_b32),
                            E(add3_u32), E(ffbl_b32), E(cmp_ne_u32), E(cmp_gt_f32_sgpr), E(mul_hi_u32), E(mul_u32_u24), E(sub_u32), E(or3_b32), E(lshl_or_b32), E(cvt_i32_f32), E(floor_f32),
-                           E(cvt_f32_fp8), E(fma_mix_all_f32), E(cmp_nop_cndmask)};
+                           E(cvt_f32_fp8), E(fma_mix_all_f32), E(cmp_nop_cndmask),
+                           E(mix_fma_max3), E(mix_fma_fmamix), E(mix_or_cmp), E(mix_max3_perm), E(mix_fma_rcp), E(mix_max3_rcp)};
   const int iters = 20000;
   printf("# %s, %d CUs, %d waves per SIMD, nominal clock %d MHz; 64 instructions per loop iteration (+ ~3 of loop overhead), %d iterations\n", prop.name, cus, occ, khz / 1000, iters);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
