@@ -789,7 +789,7 @@ __device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv
   DR_MARK("node_end");
 }
 
-template <bool COUNT, class Sign>
+template <bool COUNT, class Sign, bool POP = true>      // POP false: the lane moved on when it found this leaf (kernels_render.hip DR_LEAF_POSTPONE); only the test is left
 __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, V3 inv, const Sign& sg, Trav& tr, WideStack& ws, const int* __restrict__ stack, Ctr& c) {
   auto f = [](unsigned v) { return __uint_as_float(v); };
   DR_MARK("leaf_begin");
@@ -803,7 +803,7 @@ __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, 
     const int slot = info & ((1 << WALK_SLOT_BITS) - 1);
     if (t > 0.0f && (t < tr.best_t || (t == tr.best_t && (unsigned)slot < (unsigned)tr.best_slot))) { tr.best_t = t; tr.best_slot = slot; }
   }
-  wide_pop(tr, ws, stack);
+  if (POP) wide_pop(tr, ws, stack);
   DR_MARK("leaf_end");
 }
 

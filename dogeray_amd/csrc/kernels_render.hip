@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 #ifndef DR_PHASE_HOME
 #define DR_PHASE_HOME (!DR_WAVE_LOG_DETAIL)           // wide walk: colour, pixel, sample and frame live in the phase stash outside the phase (0: in registers, as before)
 #endif
+#ifndef DR_LEAF_POSTPONE
+#define DR_LEAF_POSTPONE 0        // lean build: a lane that reaches a leaf keeps it pending and goes on with node steps (speculative: its bound is stale until the leaf is tested)
+#endif
 #ifndef DR_SIGN_MASKS
 #define DR_SIGN_MASKS 1           // wide walk: near / far planes selected with per-lane sign words and v_bitop3 (device_core.hpp SignMask; 0: compare + v_cndmask per step)
 #endif
@@ -171,10 +174,12 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   const int d_home = region;
   unsigned long long d_want_give = 0, d_idle = 0, d_owner_walk = 0, d_share_iters = 0, d_wait_owner = 0, d_pending = 0;   // ... of the iterations in which the sharing block ran: givers, idle lanes, walking owners, owners waiting for helpers, lanes waiting for a phase
   unsigned long long d_phases = 0, d_given = 0, d_walking = 0, d_phase_ticks = 0;      // -DDR_WAVE_LOG_DETAIL builds: phases, hand-overs, walking lanes summed, ticks inside phases, all after the queue ran empty
+  constexpr bool POSTPONE = WIDE && !COOP && DR_LEAF_POSTPONE;
+  int pend = -1;                   // POSTPONE: the leaf (record << 1 | 1) this lane has found and not yet tested
   ParkedLeaf pk; pk.v0x = 0; pk.C = pk.D = u32x4{0, 0, 0, 0}; pk.info = 0; pk.parked = false;   // PARK_MIN > 0 only
   for (;;) {
     DR_MARK("loop_top");
-    const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
+    const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked) || (POSTPONE && pend >= 0));
     if (COUNT) n_iter++;
     if (WAVE_LOG && r_empty != 0ull) n_after++;
     if (DR_WAVE_LOG_DETAIL) d_iters++;
@@ -203,13 +208,13 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
     }
     const bool waits_for_helpers = WIDE && COOP && share == 64;      // (only ever true with tr.node == -1 here or while still walking)
     // (a holding wave -- long pixels, helpers walking for them -- shades as soon as a ray is finished: its pixels' latency is the point)
-    if ((__popcll(walking) < TRAV_MIN || (WIDE && COOP && held)) && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers) || tr.node == -2) != 0ull)) {
+    if ((__popcll(walking) < TRAV_MIN || (WIDE && COOP && held)) && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers && !(POSTPONE && pend >= 0)) || tr.node == -2) != 0ull)) {
       unsigned long long t0 = 0;
       DR_MARK("phase_begin");
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
       unsigned long long d_t0 = 0;
       if (DR_WAVE_LOG_DETAIL && r_empty != 0ull) { d_phases++; d_t0 = __builtin_amdgcn_s_memrealtime(); }
-      const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked) && !waits_for_helpers;
+      const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked) && !waits_for_helpers && !(POSTPONE && pend >= 0);
       if (COUNT) n_shaded += __popcll(__ballot(shade_me));
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
       constexpr bool BOUNCE_HOME = WIDE && !COOP && DR_PHASE_HOME;      // lean build: the bounce count lives in stash word 9 (one register more for the walk)
@@ -517,7 +522,36 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         }
       }
     }
-    if (WIDE) {
+    if (POSTPONE) {
+      // ---- leaf postponing: a lane that reaches a leaf takes it along (`pend`) and goes on with the next record of its stack; it stands still only
+      // with a SECOND leaf in hand.  Node steps run for the lanes that would otherwise wait at a leaf; what they visit with a bound that does not
+      // know the pending leaf's hit yet is a superset, and the result -- the lexicographic minimum over the leaves tested -- is the same.
+#ifdef DR_PARK_THR
+      constexpr int park_thr = DR_PARK_THR;
+#else
+      constexpr int park_thr = PARK_MIN > 0 ? PARK_MIN : 1;
+#endif
+      const bool draining = cur_tile >= ntiles;
+      for (int u = 0; u < P_UNROLL; u++) {
+        if (tr.node >= 0 && (tr.node & 1) && pend < 0) { pend = tr.node; wide_pop(tr, ws, my_stack); }
+        const bool has_leaf = pend >= 0, at_node = tr.node >= 0 && !(tr.node & 1);
+        const unsigned long long leaves = __ballot(has_leaf), nodes = __ballot(at_node);
+        const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= park_thr || nodes == 0ull || draining);
+        if (COUNT) { n_leafstep += do_leaves; n_nodestep += nodes != 0ull && !do_leaves; }
+        if (do_leaves) {
+          if (has_leaf) {
+            const WideRec r = wide_fetch(walk, pend);
+            wide_leaf_compute<COUNT, decltype(sg), false>(r, path.rayo, path.raydir, inv, sg, tr, ws, my_stack, c);
+            pend = -1;
+            steps++;
+          }
+        } else if (at_node) {
+          const WideRec r = wide_fetch(walk, tr.node);
+          wide_node_compute<COUNT>(r, path.rayo, inv, wr, sg, tr, ws, my_stack, c);
+          steps++;
+        }
+      }
+    } else if (WIDE) {
       // ---- one record per walking lane.  Lanes at a leaf (exact box + primitive: the long block) wait until enough of
       // them stand at one, or nobody can take a node step; when they go, they fetch together with the lanes at nodes, so
       // the wave waits for one round trip, not two.
