@@ -208,7 +208,12 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
     }
     const bool waits_for_helpers = WIDE && COOP && share == 64;      // (only ever true with tr.node == -1 here or while still walking)
     // (a holding wave -- long pixels, helpers walking for them -- shades as soon as a ray is finished: its pixels' latency is the point)
-    if ((__popcll(walking) < TRAV_MIN || (WIDE && COOP && held)) && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers && !(POSTPONE && pend >= 0)) || tr.node == -2) != 0ull)) {
+#ifdef DR_TRAV_THR
+    constexpr int trav_thr = DR_TRAV_THR;            // experiment builds
+#else
+    constexpr int trav_thr = TRAV_MIN;
+#endif
+    if ((__popcll(walking) < trav_thr || (WIDE && COOP && held)) && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers && !(POSTPONE && pend >= 0)) || tr.node == -2) != 0ull)) {
       unsigned long long t0 = 0;
       DR_MARK("phase_begin");
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
