@@ -557,6 +557,9 @@ __device__ __forceinline__ float ubyte_f(unsigned w, int k) { return (float)((w 
 #ifndef DR_NODE_V2
 #define DR_NODE_V2 1
 #endif
+#ifndef DR_NODE_MIX
+#define DR_NODE_MIX 1        // planes through v_fma_mix_f32 (0: v_cvt_f32_ubyteN + v_fma_f32)
+#endif
 #ifndef DR_NODE_BFOLD
 #define DR_NODE_BFOLD 1      // 0: b = (origin - o) * inv -+ m as before (three registers fewer, six instructions more)
 #endif
@@ -653,7 +656,11 @@ __device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u3
 #endif
 #if DR_WIDE_FOLD && DR_NODE_V2
   const float tcap = best_t;
+#if DR_NODE_MIX
   const float ax = sx24 * inv.x, ay = sy24 * inv.y, az = sz24 * inv.z;
+#else
+  const float ax = (sx24 * 0x1p-24f) * inv.x, ay = (sy24 * 0x1p-24f) * inv.y, az = (sz24 * 0x1p-24f) * inv.z;
+#endif
 #if DR_NODE_BFOLD
   (void)o;
   const float bxn = __builtin_fmaf(ox, inv.x, -wr.on.x), bxf = __builtin_fmaf(ox, inv.x, -wr.of.x);
@@ -663,12 +670,20 @@ __device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u3
   const float bx = (ox - o.x) * inv.x, by = (oy - o.y) * inv.y, bz = (oz - o.z) * inv.z;
   const float bxn = bx - wr.marg.x, bxf = bx + wr.marg.x, byn = by - wr.marg.y, byf = by + wr.marg.y, bzn = bz - wr.marg.z, bzf = bz + wr.marg.z;
 #endif
+#if DR_NODE_MIX
   const PlanePairs pnx = plane_pairs(nxw), pfx = plane_pairs(fxw), pny = plane_pairs(nyw), pfy = plane_pairs(fyw), pnz = plane_pairs(nzw), pfz = plane_pairs(fzw);
+#endif
 #pragma unroll
   for (int k = 0; k < 4; k++) {
+#if DR_NODE_MIX
     const float t0x = plane_t(pnx, k, ax, bxn), t1x = plane_t(pfx, k, ax, bxf);
     const float t0y = plane_t(pny, k, ay, byn), t1y = plane_t(pfy, k, ay, byf);
     const float t0z = plane_t(pnz, k, az, bzn), t1z = plane_t(pfz, k, az, bzf);
+#else      // experiment: conversion (the "other" pipe) + plain fma (the fp32 pipe, which issues beside it) instead of v_fma_mix_f32 + unpacking
+    const float t0x = __builtin_fmaf(ubyte_f(nxw, k), ax, bxn), t1x = __builtin_fmaf(ubyte_f(fxw, k), ax, bxf);
+    const float t0y = __builtin_fmaf(ubyte_f(nyw, k), ay, byn), t1y = __builtin_fmaf(ubyte_f(fyw, k), ay, byf);
+    const float t0z = __builtin_fmaf(ubyte_f(nzw, k), az, bzn), t1z = __builtin_fmaf(ubyte_f(fzw, k), az, bzf);
+#endif
 #else
   const float tcap = __builtin_fminf(best_t, 10000.0f);
   const float sx = sx24 * 0x1p-24f, sy = sy24 * 0x1p-24f, sz = sz24 * 0x1p-24f;
