@@ -542,7 +542,7 @@ __device__ __forceinline__ float ubyte_f(unsigned w, int k) { return (float)((w 
 #ifndef DR_WIDE_FOLD
 #define DR_WIDE_FOLD 1
 #endif
-// DR_NODE_V2 (default, round 3): the same folded test with fewer instructions per node step (152 -> 128 VALU):
+// DR_NODE_V2 (default, round 3): the same folded test, cheaper (with the sign words and the sign-based pass below: 539 -> 446 SIMD cycles per node step):
 //  * a plane byte is read as the f16 DENORMAL byte * 2^-24 (half-word 0x00bb) and the node record stores scale * 2^24 (device_layout.h), so that
 //    v_fma_mix_f32 converts the byte on the fly: fma(byte * 2^-24, (scale * 2^24) * inv, b) is the SAME real number rounded once as
 //    fma(byte, scale * inv, b) -- one instruction per plane instead of a conversion and an fma, and two plane bytes are unpacked by one
