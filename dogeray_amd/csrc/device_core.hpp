@@ -174,6 +174,32 @@ __device__ __forceinline__ V3 rand_in_unit_disk(Xorwow& r) {     // K:988-994
   }
 }
 
+// One rejection loop for a whole wave: lanes with kind 3 draw a point in the unit sphere (K:640-648: three uniforms per candidate, in double, x y z),
+// lanes with kind 2 a point in the unit disk (K:988-994: two uniforms per candidate, in float), lanes with kind 0 nothing -- each lane's sequence of
+// draws is exactly that of rand_in_unit_sphere / rand_in_unit_disk, but the wave runs the loop once, for as many turns as its unluckiest lane needs,
+// instead of once per kind (the persistent kernel's shade / refill phase: the lanes that scatter and the lanes that start a path).
+__device__ __forceinline__ V3 rand_points_merged(Xorwow& r, int kind) {
+#if !DR_UNIFORM_V2
+  return kind == 3 ? rand_in_unit_sphere(r) : (kind == 2 ? rand_in_unit_disk(r) : mk(0, 0, 0));
+#else
+  V3 p = mk(0, 0, 0);
+  bool todo = kind != 0;
+  while (todo) {
+    const double zx = r.z_plus_half(), zy = r.z_plus_half();
+    float x, y, z = 0.0f;
+    if (kind == 3) {
+      x = (float)__builtin_fma(zx, 0x1p-52, -1.0); y = (float)__builtin_fma(zy, 0x1p-52, -1.0);
+      z = r.uniform_pm1();
+    } else {
+      x = (float)(zx * 0x1p-53) * 2 - 1; y = (float)(zy * 0x1p-53) * 2 - 1;      // randy() * 2 - 1
+    }
+    p = mk(x, y, z);
+    todo = outside_unit(dot(p, p));
+  }
+  return p;
+#endif
+}
+
 // ------------------------------------------------------------------ intersection
 // Which plane of a box a ray meets first depends on the sign of 1/direction only (aabb2's swap, K:262-266).  SignCmp decides by comparing, as
 // the reference does.  SignMask (persistent kernel) keeps the outcome of those three comparisons as per-lane words, all ones or all zeros,
@@ -1029,11 +1055,16 @@ __device__ __forceinline__ V3 surface_normal(float4 pA, float4 pB, float4 pC, fl
 // (K:807-950), shade_miss = the background branch (K:951-976).
 struct Path { V3 rayo, raydir, atten; };
 
-// Returns true when the path continues (rayo/raydir/atten updated), false when it ends at an
-// emissive surface with `emitted` as its radiance (K:941-944).
+// shade_hit in three parts, so that the persistent kernel can run ONE rejection loop per phase for the lanes that scatter and the lanes that start a
+// path (rand_points_merged): everything up to the draws (shade_prepare: K:807-848 and glossy's one uniform), the point in the unit sphere, and the
+// scatter itself (shade_scatter: K:848-944).  A lane's draws keep the reference's order.
+struct ShadeCtx { V3 hitpoint, N, ocolor; float add_x, rough, ir, r5; int mat; bool front; };
+__device__ __forceinline__ bool shade_needs_sphere(const ShadeCtx& sc) { return sc.mat == 0 || sc.mat == 3 || sc.mat == 5; }
+
+// Returns false when the path ends at an emissive surface, with `emitted` as its radiance (K:941-944); true: sc is filled
 template <bool COUNT>
-__device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, float t, int slot, Xorwow& rng, Ctr& c, V3& emitted) {
-  V3& rayo = path.rayo; V3& raydir = path.raydir; V3& atten = path.atten;
+__device__ __forceinline__ bool shade_prepare(const RenderParams& P, const Path& path, float t, int slot, Xorwow& rng, Ctr& c, ShadeCtx& sc, V3& emitted) {
+  const V3 rayo = path.rayo, raydir = path.raydir;
   if (COUNT) c.S++;
   V3 hitpoint = rayo + splat(t) * raydir;
   const float4* pp = reinterpret_cast<const float4*>(P.prims + slot);
@@ -1061,18 +1092,25 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, flo
     uint32_t px = tex_fetch<COUNT>(P.tex, P.texels, rtexnum, texco.x, -texco.y + 1, c);
     rough = float(px & 255u) / 255 / 2;
   }
-  // ---- scatter K:848-944.  The random draws come first, ONE copy of each loop for every lane that needs it: diffuse (0),
-  // metal (3) and glossy (5) all draw a point in the unit sphere, glossy after its one uniform -- the order of draws
-  // of each lane is the reference's, but a wave runs the rejection loop once instead of once per material branch (the
-  // five copies of that loop were most of the shade phase: 106 VALU instructions per turn, 27 of them f64).
-  float r5 = 0.0f;
-  if (mat == 5) r5 = randy(rng);
-  V3 rs = mk(0, 0, 0);
-  if (mat == 0 || mat == 3 || mat == 5) rs = rand_in_unit_sphere(rng);
-  const bool like_metal = mat == 3 || (mat == 5 && r5 > 0.8);      // float compared with the double 0.8
+  if (!(mat == 0 || mat == 2 || mat == 3 || mat == 4 || mat == 5)) { emitted = ocolor * path.atten; return false; }      // emissive (and every unknown material) K:941-944
+  // ---- the random draws come first (K:848-944), ONE copy of each loop for every lane that needs it: diffuse (0), metal (3) and glossy (5) all draw
+  // a point in the unit sphere, glossy after its one uniform -- the order of draws of each lane is the reference's, but a wave runs the rejection
+  // loop once instead of once per material branch (the five copies of that loop were most of the shade phase)
+  sc.r5 = 0.0f;
+  if (mat == 5) sc.r5 = randy(rng);
+  sc.hitpoint = hitpoint; sc.N = N; sc.ocolor = ocolor; sc.add_x = add_x; sc.rough = rough; sc.ir = s5.z; sc.mat = mat; sc.front = front;      // ir: b[g].addional.y itself, not the textured roughness (K:917)
+  return true;
+}
+
+// the scatter of one bounce (rs: the point in the unit sphere, for the materials that draw one): rayo / raydir / atten updated
+__device__ __forceinline__ void shade_scatter(Path& path, const ShadeCtx& sc, V3 rs, Xorwow& rng) {
+  V3& rayo = path.rayo; V3& raydir = path.raydir; V3& atten = path.atten;
+  const V3 hitpoint = sc.hitpoint, N = sc.N, ocolor = sc.ocolor;
+  const int mat = sc.mat;
+  const bool like_metal = mat == 3 || (mat == 5 && sc.r5 > 0.8);      // float compared with the double 0.8
   if (mat == 0 || (mat == 5 && !like_metal)) {
     V3 target = hitpoint + N;
-    if (mat == 5 || add_x == 0) target = target + rs;              // glossy never normalises (K:899)
+    if (mat == 5 || sc.add_x == 0) target = target + rs;              // glossy never normalises (K:899)
     else target = target + normalized(rs);
     atten = atten * ocolor;
     rayo = hitpoint;
@@ -1085,10 +1123,10 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, flo
     V3 refl = reflect(normalized(raydir), N);
     atten = atten * ocolor;
     rayo = hitpoint;
-    raydir = refl + splat(rough) * rs;
-  } else if (mat == 4) {
-    float ir = s5.z;                         // b[g].addional.y itself, not the textured roughness (K:917)
-    float ratio = front ? (1.0f / ir) : ir;
+    raydir = refl + splat(sc.rough) * rs;
+  } else {      // mat == 4
+    float ir = sc.ir;
+    float ratio = sc.front ? (1.0f / ir) : ir;
     float cos_theta = (float)fmin((double)dot(normalized(raydir) * splat(-1.0f), N), 1.0);
     float sin_theta = (float)__builtin_sqrt(1.0 - (double)(cos_theta * cos_theta));
     bool cannot = (ratio * sin_theta) > 1.0f;
@@ -1098,9 +1136,18 @@ __device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, flo
     atten = atten * ocolor;
     rayo = hitpoint;
     raydir = out;
-  } else {
-    { emitted = ocolor * atten; return false; }
   }
+}
+
+// Returns true when the path continues (rayo/raydir/atten updated), false when it ends at an
+// emissive surface with `emitted` as its radiance (K:941-944).
+template <bool COUNT>
+__device__ __forceinline__ bool shade_hit(const RenderParams& P, Path& path, float t, int slot, Xorwow& rng, Ctr& c, V3& emitted) {
+  ShadeCtx sc;
+  if (!shade_prepare<COUNT>(P, path, t, slot, rng, c, sc, emitted)) return false;
+  V3 rs = mk(0, 0, 0);
+  if (shade_needs_sphere(sc)) rs = rand_in_unit_sphere(rng);
+  shade_scatter(path, sc, rs, rng);
   return true;
 }
 
@@ -1138,15 +1185,23 @@ __device__ __forceinline__ V3 trace_path(const RenderParams& P, const Closest& c
   return mk(0, 0, 0);
 }
 
-// Camera ray of one sample: K:1065-1073 (rng must be freshly seeded).
-__device__ __forceinline__ void camera_ray(const RenderParams& P, int x, int y, Xorwow& rng, V3& origin, V3& dir) {
+// Camera ray of one sample: K:1065-1073 (rng must be freshly seeded), in two parts around the point in the unit disk (the persistent kernel draws
+// it in the phase's one rejection loop, rand_points_merged)
+__device__ __forceinline__ void camera_prepare(const RenderParams& P, int x, int y, Xorwow& rng, float& nu, float& nv) {
+  nu = (float)(((double)(float)x + rng.uniform_double()) / P.den_w);
+  nv = (float)(((double)(float)y + rng.uniform_double()) / P.den_h);
+}
+__device__ __forceinline__ void camera_finish(const RenderParams& P, float nu, float nv, V3 disk, V3& origin, V3& dir) {
   V3 from = ld3(P.from), llc = ld3(P.llc), hor = ld3(P.hor), ver = ld3(P.ver), uu = ld3(P.uu), vu = ld3(P.vu);
-  float nu = (float)(((double)(float)x + rng.uniform_double()) / P.den_w);
-  float nv = (float)(((double)(float)y + rng.uniform_double()) / P.den_h);
-  V3 rd = splat(P.lens_radius) * rand_in_unit_disk(rng);
+  V3 rd = splat(P.lens_radius) * disk;
   V3 offset = uu * splat(rd.x) + vu * splat(rd.y);
   dir = llc + splat(nu) * hor + splat(nv) * ver - from - offset;
   origin = from + offset;
+}
+__device__ __forceinline__ void camera_ray(const RenderParams& P, int x, int y, Xorwow& rng, V3& origin, V3& dir) {
+  float nu, nv;
+  camera_prepare(P, x, y, rng, nu, nv);
+  camera_finish(P, nu, nv, rand_in_unit_disk(rng), origin, dir);
 }
 __device__ __forceinline__ uint64_t sample_seed(const RenderParams& P, int x, int y, int s, int frame = 0) {   // K:1065 with clock() := frame seed
   return P.seed + (uint64_t)frame * P.batch_seed_stride + (uint64_t)s * 0x9E3779B97F4A7C15ull +

@@ -78,6 +78,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 #ifndef DR_PHASE_HOME
 #define DR_PHASE_HOME (!DR_WAVE_LOG_DETAIL)           // wide walk: colour, pixel, sample and frame live in the phase stash outside the phase (0: in registers, as before)
 #endif
+#ifndef DR_MERGED_DRAWS
+#define DR_MERGED_DRAWS 1         // one rejection loop per shade / refill phase for sphere and disk points together (0: one each, as before)
+#endif
 #ifndef DR_LEAF_POSTPONE
 #define DR_LEAF_POSTPONE 0        // lean build: a lane that reaches a leaf keeps it pending and goes on with node steps (speculative: its bound is stale until the leaf is tested)
 #endif
@@ -257,15 +260,24 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       DR_MARK("phase_shade");
       bool ended = false;
       V3 radiance = mk(0, 0, 0);
+      // (DR_MERGED_DRAWS: the hit is shaded in two parts around the phase's ONE rejection loop, which serves the lanes that scatter -- a point in the unit
+      // sphere -- and, further down, the lanes that start a path -- a point in the unit disk: device_core.hpp rand_points_merged.  A path that ends
+      // here, at an emissive surface or at the depth limit, draws nothing more: its generator is re-seeded with its next pixel.)
+      ShadeCtx sc; sc.hitpoint = sc.N = sc.ocolor = mk(0, 0, 0); sc.add_x = sc.rough = sc.ir = sc.r5 = 0.0f; sc.mat = -1; sc.front = false;
+      bool scatter_me = false;
       if (shade_me) {
         if (tr.best_slot >= 0 && tr.best_t > 0.0f) {
-          ended = !shade_hit<COUNT>(P, path, tr.best_t, tr.best_slot, rng, c, radiance);
-          if (!ended) {
+          if (!shade_prepare<COUNT>(P, path, tr.best_t, tr.best_slot, rng, c, sc, radiance)) ended = true;
+          else {
             if (BOUNCE_HOME) bounce = __float_as_int(st[9 * 64]);
             bounce++;
             if (bounce >= P.max_depth) ended = true;        // depth exhausted: black (K:981)
+            else scatter_me = true;
             if (BOUNCE_HOME) st[9 * 64] = __int_as_float(bounce);
           }
+#if !DR_MERGED_DRAWS
+          if (scatter_me) { shade_scatter(path, sc, shade_needs_sphere(sc) ? rand_in_unit_sphere(rng) : mk(0, 0, 0), rng); scatter_me = false; }
+#endif
         } else {
           radiance = shade_miss<COUNT>(P, path, c);
           ended = true;
@@ -387,6 +399,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
       // ---- start the next path of every lane that has a pixel and no path
       DR_MARK("phase_camera");
+      bool new_path = false;
+      float cam_nu = 0.0f, cam_nv = 0.0f;
       if (tr.node == -2 && px >= 0) {
         if (degenerate) {
           sample = 0x7fffffff;                     // nothing to trace: the pixel is stored as 0 next round
@@ -394,7 +408,20 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         } else {
           rng.init(sample_seed(P, px, py, sample, frame));
           if (COUNT) { c.samples++; c.rays++; }
-          camera_ray(P, px, py, rng, path.rayo, path.raydir);
+          camera_prepare(P, px, py, rng, cam_nu, cam_nv);
+          new_path = true;
+        }
+      }
+      {
+        // ---- the phase's rejection loop, once for the wave: sphere points for the lanes that scatter, disk points for the lanes that start a path
+#if DR_MERGED_DRAWS
+        const V3 pt = rand_points_merged(rng, scatter_me && shade_needs_sphere(sc) ? 3 : (new_path ? 2 : 0));
+#else
+        const V3 pt = new_path ? rand_in_unit_disk(rng) : mk(0, 0, 0);
+#endif
+        if (scatter_me) shade_scatter(path, sc, pt, rng);
+        if (new_path) {
+          camera_finish(P, cam_nu, cam_nv, pt, path.rayo, path.raydir);
           path.atten = splat(1.0f);
           bounce = 0;
           if (BOUNCE_HOME) st[9 * 64] = __int_as_float(0);
