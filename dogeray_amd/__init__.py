@@ -124,10 +124,8 @@ _API = [
     ("dr_stats_enable_counters", C.c_int, [_VP, C.c_int]),
     ("dr_stats_reset", C.c_int, [_VP]),
     ("dr_stats_get", C.c_int, [_VP, C.POINTER(DrStats)]),
-    ("dr_stats_kernel_diag", C.c_int, [_VP, C.POINTER(C.c_ulonglong), C.c_int]),
     ("dr_stats_wave_log", C.c_int, [_VP, C.POINTER(C.c_ulonglong), C.c_int, C.POINTER(C.c_int)]),
     ("dr_stats_pixel_cost", C.c_int, [_VP, C.POINTER(C.c_uint), C.c_size_t, C.POINTER(C.c_size_t)]),
-    ("dr_stats_pixel_times", C.c_int, [_VP, C.POINTER(C.c_uint), C.c_size_t, C.POINTER(C.c_size_t)]),
     ("dr_context_probe_gather", C.c_int, [_VP, C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
     ("dr_kat_rng", C.c_int, [_VP, C.c_uint64, C.c_int, _VP]),
     ("dr_kat_aabb", C.c_int, [_VP, C.c_int] + [_VP] * 6),
@@ -314,7 +312,7 @@ class Context:
         _check(lib().dr_context_set_traversal(self._h, mode))
 
     def set_option(self, name, value):
-        """Tuning knob ("kernel", "batch_frames", "feedback", "occupancy", "trav_min", "park_min"); never changes a pixel."""
+        """Tuning knob ("kernel", "batch_frames", "feedback", "occupancy", "schedule", ...: include/dogeray_amd.h); never changes a pixel."""
         _check(lib().dr_context_set_option(self._h, name.encode(), int(value)))
 
     def get_option(self, name):
@@ -424,12 +422,6 @@ class Context:
         _check(lib().dr_stats_get(self._h, C.byref(s)))
         return s.as_dict()
 
-    def kernel_diag(self, n=16):
-        """Diagnostic words of the pool kernel's counting build (option pool_diag), see dr_stats_kernel_diag."""
-        buf = (C.c_ulonglong * n)()
-        _check(lib().dr_stats_kernel_diag(self._h, buf, n))
-        return [int(v) for v in buf]
-
     def wave_log(self, max_waves=16384):
         """(n, 16) uint64: begin, queue-empty, end stamps (100 MHz ticks) and iterations after the queue was empty, per wave of the
         last persistent launch; needs set_option("wave_log", 1) before the launch."""
@@ -447,17 +439,6 @@ class Context:
         if n.value < out.size:
             return np.zeros((0, 0), dtype=np.uint32)
         return out.reshape(gx, gy, 8, 8).transpose(0, 2, 1, 3).reshape(gx * 8, gy * 8)[:W, :H]
-
-    def pixel_times(self, W, H):
-        """Experiment builds only: two (W, H) uint32 maps, start and end of every pixel of the last single-frame launch in 100 MHz
-        ticks since the launch began (None in the product build)."""
-        gx, gy = (W + 7) // 8, (H + 7) // 8
-        out = np.zeros(2 * gx * gy * 64, dtype=np.uint32)
-        n = C.c_size_t()
-        _check(lib().dr_stats_pixel_times(self._h, out.ctypes.data_as(C.POINTER(C.c_uint)), out.size, C.byref(n)))
-        if n.value < out.size:
-            return None
-        return tuple(h.reshape(gx, gy, 8, 8).transpose(0, 2, 1, 3).reshape(gx * 8, gy * 8)[:W, :H] for h in (out[:gx * gy * 64], out[gx * gy * 64:]))
 
     def probe_gather(self, hot_records=0, iters=2000):
         """Records/s of divergent, dependent 64-byte fetches from the resident wide array (bench.py roofline.gather)."""

@@ -41,17 +41,6 @@ struct dr_context {
   uint8_t* present = nullptr; size_t present_bytes = 0;
   // multi-GPU gather: two packed copies of this context's stripe (double buffer), sized for the accumulator
   int32_t* packed[2] = {nullptr, nullptr}; size_t packed_elems[2] = {0, 0};
-  void* paths = nullptr; size_t paths_waves = 0;        // experimental kernels: path records in global memory (16-byte units)
-  unsigned* abort_flag = nullptr;                        // experimental roles kernel: set by a wave that waited too long (protocol failure)
-  bool abort_used = false;                               // a launch that may set it has been queued since the last check
-  int pool = 0;             // -DDOGERAY_EXPERIMENTAL builds, wide walk: 1 = long launches run the pool kernel (kernels_pool.hip: measured slower), 2 = every launch it can render, 0 = never
-  int pool_diag = 0;        // pool kernel: the build with the per-stage diagnostics (dr_stats_kernel_diag)
-  int pool_shape = 0;       // pool kernel: 0 = 4 stack words per path in LDS and 15 waves per CU, 1 = 3 words and 16 waves, 2 = 8 words and 12 waves
-  int pool_shade_min = 48;  // pool kernel: a wave shades once this many of its 128 paths wait for it
-  unsigned* pool_scratch = nullptr; size_t pool_scratch_words_have = 0;
-  int roles = 0;            // wide walk, long launches: 3 / 7 = workgroups of that many trace waves + one shade wave, 6 = 6 + 2 (render_roles_kernel)
-  int paired = 0;           // wide walk, long launches: 1 = two paths per lane (render_paired_kernel: measured slower), 0 = the one-path kernel
-  int pair_thresh = 48;     // ... phase once this many lanes have a path to service (32, 48 or 56)
   unsigned long long* counters = nullptr;
   unsigned* tile_counters = nullptr; int tile_cursor = 0; int num_cus = 256;
   // cost feedback (persistent kernel): per-pixel cost of the last frame, per-tile cost, tile order
@@ -69,9 +58,7 @@ struct dr_context {
   // tunables (dr_context_set_option / DOGERAY_OPTIONS)
   int kernel = DR_KERNEL_PERSISTENT;
   int occupancy = 6;        // waves per SIMD the kernel is built and launched for (persistent: 4, 5, or 6 = six for the lean wide build and five for the others; tile kernel: 4 or 6)
-  int trav_min = 32;        // persistent kernel: shade/refill once fewer lanes than this are walking
-  int park_min = 20;        // persistent kernel: leaf steps (parked leaves) once this many lanes stand at one (0 = on the spot)
-  int unroll = 2;           // persistent kernel: node steps per loop iteration
+  int schedule = 0;         // persistent kernel: 0 = shade / refill below 32 walking lanes, leaf steps for 20 lanes, two steps per iteration (tuned); 1 = 32 / 8 / 1; 2 = 48 / leaves on the spot / 1
   int xcd_regions = 1;      // persistent kernel: one tile queue per XCD (image bands), with stealing
   int heavy_factor = 1;     // tile order: tiles costlier than this x the mean start first, the rest keep their natural order (0 = all natural, -1 = all by cost)
   int coop_steps = 2;       // persistent kernel, drain phase: rays older than this many steps are shared with idle lanes / finished cooperatively (0 = off)
@@ -107,6 +94,7 @@ struct dr_context {
   hipEvent_t pipe_barrier = nullptr; bool pipe_barrier_set = false;      // end of the newest tile-order refresh: later launches read that order
   hipEvent_t pipe_sync = nullptr;                  // orders the pipeline after earlier work on `stream`
   bool pipe_dirty = false;                         // frames have gone through the pipeline since the last join
+  bool pipe_ready = false;                         // every stream and event of the pipeline exists (pipeline_setup)
   bool pipe_hold_order = false;                    // enqueue_frame: use the stored tile order as it is, record no costs (a launch beside another one)
 };
 
@@ -202,67 +190,16 @@ void feedback_buffers(dr_context* c, const RenderParams& P, int tiles, const int
   pcost = c->pixel_cost;
 }
 
-bool ensure_abort_flag(dr_context* c);
-inline bool long_launch(const dr_context* c, const RenderParams& P);
-// the pool kernel renders this launch: wide walk resident, a long launch, the non-counting build, and its buffers are to be had
-bool use_pool(dr_context* c, const RenderParams& P) {
-  if (!c->pool || !experimental_built() || c->count || traversal_of(c) != DR_TRAVERSAL_WIDE || !pool_kernel_can_render(P) || (c->pool == 1 && !long_launch(c, P))) return false;
-  const size_t need = pool_scratch_words(c->num_cus);
-  if (c->pool_scratch_words_have < need) {
-    if (c->pool_scratch) { (void)hipFree(c->pool_scratch); c->pool_scratch = nullptr; c->pool_scratch_words_have = 0; }
-    if (hipMalloc((void**)&c->pool_scratch, need * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); c->pool_scratch = nullptr; return false; }
-    c->pool_scratch_words_have = need;
-  }
-  return true;
-}
-
-// path records of the experimental kernels for `waves` waves; false if the memory is not to be had
-bool ensure_paths(dr_context* c, size_t waves) {       // `waves` x 128 path records
-  if (c->paths && c->paths_waves >= waves) return true;
-  if (c->paths) { (void)hipFree(c->paths); c->paths = nullptr; c->paths_waves = 0; }
-  if (hipMalloc((void**)&c->paths, waves * 64 * 2 * EXPERIMENTAL_PATH_UNITS * 16) != hipSuccess) { (void)hipGetLastError(); return false; }
-  c->paths_waves = waves;
-  return true;
-}
-bool ensure_abort_flag(dr_context* c) {
-  if (c->abort_flag) return true;
-  if (hipMalloc((void**)&c->abort_flag, sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); c->abort_flag = nullptr; return false; }
-  (void)hipMemsetAsync(c->abort_flag, 0, sizeof(unsigned), c->stream);
-  return true;
-}
-
 PersistentCfg persistent_cfg(const dr_context* c) {
   PersistentCfg cfg;
-  cfg.traversal = traversal_of(c); cfg.occupancy = c->occupancy; cfg.trav_min = c->trav_min; cfg.park_min = c->park_min; cfg.unroll = c->unroll;
+  cfg.traversal = traversal_of(c); cfg.occupancy = c->occupancy; cfg.schedule = c->schedule;
   cfg.num_cus = c->num_cus; cfg.coop_tiles_per_wave = c->coop_tiles_per_wave; cfg.count = c->count;
   return cfg;
 }
 
-// a launch with many tiles per wave: its tail does not show (the lean builds, the pool kernel; short launches run the work-sharing build)
+// a launch with many tiles per wave: its tail does not show (the lean build; short launches run the work-sharing build)
 inline bool long_launch(const dr_context* c, const RenderParams& P) {
   return (long long)P.ncols * P.gy * P.batch >= (long long)c->coop_tiles_per_wave * c->num_cus * 20;
-}
-
-// the experimental kernels of -DDOGERAY_EXPERIMENTAL builds (options "roles", "paired"); false: not built, or not for this launch
-bool enqueue_experimental(dr_context* c, const RenderParams& P, unsigned* counter, const int* order, unsigned* pcost, bool& used_feedback) {
-  used_feedback = false;
-  if (!experimental_built() || traversal_of(c) != DR_TRAVERSAL_WIDE || c->count || P.max_depth <= 0 || !(P.spp_f > 0.0f)) return false;
-  if (c->roles && long_launch(c, P)) {
-    const int blocks = roles_blocks(c->roles, c->num_cus);
-    if (!ensure_paths(c, roles_path_waves(c->roles, blocks)) || !ensure_abort_flag(c)) return false;
-    if (!launch_roles_kernel(c->stream, P, c->roles, blocks, counter, c->paths, c->abort_flag)) return false;
-    c->abort_used = true;
-    return true;
-  }
-  const long long work = (long long)P.ncols * P.gy * P.batch;
-  int blocks = c->num_cus * 5;
-  if ((long long)blocks * 4 > work) blocks = (int)((work + 3) / 4);
-  const bool coop = P.coop_steps > 0 && work < (long long)c->coop_tiles_per_wave * blocks * 4;
-  if (c->paired && !coop && c->occupancy >= 5 && ensure_paths(c, (size_t)blocks * 4)) {
-    used_feedback = true;
-    return launch_paired_kernel(c->stream, P, blocks, c->pair_thresh, counter, order, order ? c->region_start : nullptr, pcost, c->paths);
-  }
-  return false;
 }
 
 // enqueue one launch (P.batch frames); no events, no sync
@@ -276,8 +213,6 @@ void enqueue_frame(dr_context* c, const RenderParams& P_in) {
     }
     unsigned* counter = c->tile_counters + c->tile_cursor;      // one counter per region
     c->tile_cursor += MAX_REGIONS;
-    bool fb = false;
-    if (c->roles && enqueue_experimental(c, P, counter, nullptr, nullptr, fb)) return;
     const int* order; unsigned* pcost;
     if (c->pipe_hold_order) {
       // a pipelined launch runs beside the previous frame's: it may read the tile order but nobody may write it (or the costs) meanwhile
@@ -285,15 +220,8 @@ void enqueue_frame(dr_context* c, const RenderParams& P_in) {
       order = (c->order_valid && c->order_capacity >= tiles && memcmp(c->order_key + 13, geom, sizeof(geom)) == 0) ? c->tile_order : nullptr;
       pcost = nullptr;
     } else feedback_buffers(c, P, tiles, order, pcost);
-    if (c->paired && enqueue_experimental(c, P, counter, order, pcost, fb)) {}
-    else if (use_pool(c, P)) {
-      PoolCfg pc; pc.num_cus = c->num_cus; pc.shade_min = c->pool_shade_min; pc.shape = c->pool_shape; pc.diag = c->pool_diag != 0;
-      launch_pool_kernel(c->stream, P, pc, counter, order, order ? c->region_start : nullptr, pcost, c->pool_scratch);
-      c->wave_log_waves = 0;
-    } else {
-      if (!c->wave_log_on) P.wave_log = nullptr;
-      c->wave_log_waves = launch_persistent_kernel(c->stream, P, persistent_cfg(c), counter, order, c->region_start, pcost);
-    }
+    if (!c->wave_log_on) P.wave_log = nullptr;
+    c->wave_log_waves = launch_persistent_kernel(c->stream, P, persistent_cfg(c), counter, order, c->region_start, pcost);
     // next launch's order from this launch's costs (stream-ordered, no host sync).  The view does not change between the frames of
     // a progressive render, so after the first two launches of a view the order is refreshed every feedback_every-th launch only
     // (the two kernels take 75 us: nothing for a launch of 32 frames, 6 % of a launch of one)
@@ -314,8 +242,7 @@ int join_pipeline(dr_context* c);
 int set_option(dr_context* c, const std::string& name, int v) {
   if (name == "kernel") { if (v != DR_KERNEL_TILE && v != DR_KERNEL_PERSISTENT) goto bad; c->kernel = v; }
   else if (name == "occupancy") { if (v != 4 && v != 5 && v != 6) goto bad; c->occupancy = v; }
-  else if (name == "trav_min") { if (v != 32 && v != 48) goto bad; c->trav_min = v; }
-  else if (name == "park_min") { if (v != 0 && v != 8 && v != 16 && v != 20) goto bad; c->park_min = v; }
+  else if (name == "schedule") { if (v < 0 || v > 2) goto bad; c->schedule = v; }
   else if (name == "heavy_factor") { if (v < -1 || v > 1000) goto bad; c->heavy_factor = v; c->order_valid = false; }
   else if (name == "coop_steps") { if (v < 0) goto bad; c->coop_steps = v; }
   else if (name == "coop_lanes") { if (v < 1 || v > 64) goto bad; c->coop_lanes = v; }
@@ -327,17 +254,13 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "wave_log") {
     if (v != 0 && v != 1) goto bad;
     if (v && !c->wave_log) {
-      const size_t bytes = (size_t)WAVE_LOG_WAVES * COUNTER_WORDS * sizeof(unsigned long long) + PIXEL_LOG_WORDS * sizeof(unsigned);
+      const size_t bytes = (size_t)WAVE_LOG_WAVES * 16 * sizeof(unsigned long long);
       if (hipSetDevice(c->device) != hipSuccess || hipMalloc((void**)&c->wave_log, bytes) != hipSuccess) { c->wave_log = nullptr; set_error("cannot allocate the wave log"); return DR_ERR_DEVICE; }
       (void)hipMemsetAsync(c->wave_log, 0, bytes, c->stream);
     }
     c->wave_log_on = v;
   }
   else if (name == "coop_tiles_per_wave") { if (v < 0) goto bad; c->coop_tiles_per_wave = v; }
-  else if (name == "paired") { c->paired = v != 0; }
-  else if (name == "pool") { if (v < 0 || v > 2) goto bad; c->pool = v; }
-  else if (name == "pool_shade_min") { if (v < 1 || v > 128) goto bad; c->pool_shade_min = v; }
-  else if (name == "pool_diag") { c->pool_diag = v != 0; }
   else if (name == "pipe_streams") {
     if (v < 2 || v > dr_context::PIPE_STREAMS) goto bad;
     if (v != c->pipe_streams) {               // slots and streams are numbered by ticket: drain, then start again from ticket 0
@@ -347,11 +270,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
     }
   }
   else if (name == "pipe_lean") { c->pipe_lean = v != 0; }
-  else if (name == "pool_shape") { if (v < 0 || v > 2) goto bad; c->pool_shape = v; }
-  else if (name == "roles") { if (v != 0 && v != 3 && v != 6 && v != 7) goto bad; c->roles = v; }
-  else if (name == "pair_thresh") { if (v != 32 && v != 48 && v != 56) goto bad; c->pair_thresh = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
-  else if (name == "unroll") { if (v < 1 || v > 3) goto bad; c->unroll = v; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
   else if (name == "order_follows_camera") { c->order_follows_camera = v != 0; }
@@ -371,16 +290,6 @@ int launch_render(dr_context* c, const RenderParams& P) {
   enqueue_frame(c, P);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(c->ev1, c->stream));
-  return DR_OK;
-}
-
-int check_abort(dr_context* c) {
-  if (!c->abort_used) return DR_OK;
-  unsigned f = 0;
-  HIP_TRY(hipMemcpyAsync(&f, c->abort_flag, sizeof(f), hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  c->abort_used = false;
-  if (f) { (void)hipMemsetAsync(c->abort_flag, 0, sizeof(unsigned), c->stream); set_error("a render kernel gave up waiting on its own queues (internal protocol failure): the frame is incomplete"); return DR_ERR_DEVICE; }
   return DR_OK;
 }
 
@@ -405,16 +314,18 @@ int join_pipeline(dr_context* c) {
 }
 
 int pipeline_setup(dr_context* c) {
-  if (c->acc_stream) return DR_OK;
-  bool ok = hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking) == hipSuccess;
+  if (c->pipe_ready) return DR_OK;
+  // (a failed attempt leaves what it created in place -- dr_context_destroy releases it -- and pipe_ready false: the next call creates what is missing)
+  bool ok = c->acc_stream || hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking) == hipSuccess;
   c->pipe_stream[0] = c->stream;
-  for (int k = 1; k < dr_context::PIPE_STREAMS; k++) ok = ok && hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking) == hipSuccess;
+  for (int k = 1; k < dr_context::PIPE_STREAMS; k++) ok = ok && (c->pipe_stream[k] || hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking) == hipSuccess);
   if (!ok) { set_error("pipeline: cannot create streams"); return DR_ERR_DEVICE; }
-  for (int k = 0; k < dr_context::PIPE_DEPTH; k++)
-    ok = ok && hipEventCreateWithFlags(&c->pipe_rendered[k], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->pipe_added[k], hipEventDisableTiming) == hipSuccess;
-  for (int k = 0; k < dr_context::PIPE_STREAMS; k++) ok = ok && hipEventCreateWithFlags(&c->pipe_last[k], hipEventDisableTiming) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&c->pipe_barrier, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&c->pipe_sync, hipEventDisableTiming) == hipSuccess;
+  auto event = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
+  for (int k = 0; k < dr_context::PIPE_DEPTH; k++) ok = ok && event(c->pipe_rendered[k]) && event(c->pipe_added[k]);
+  for (int k = 0; k < dr_context::PIPE_STREAMS; k++) ok = ok && event(c->pipe_last[k]);
+  ok = ok && event(c->pipe_barrier) && event(c->pipe_sync);
   if (!ok) { set_error("pipeline: cannot create events"); return DR_ERR_DEVICE; }
+  c->pipe_ready = true;
   return DR_OK;
 }
 
@@ -490,14 +401,15 @@ int dr_context_create(int device_ordinal, dr_context** out) {
 void dr_context_destroy(dr_context* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  // every stream that may still touch the buffers, before they are freed
   if (c->stream) (void)hipStreamSynchronize(c->stream);
-  void* bufs[] = {c->pool_scratch, c->abort_flag, c->wave_log, c->paths, c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
+  for (int k = 1; k < dr_context::PIPE_STREAMS; k++) if (c->pipe_stream[k]) (void)hipStreamSynchronize(c->pipe_stream[k]);
+  if (c->acc_stream) (void)hipStreamSynchronize(c->acc_stream);
+  void* bufs[] = {c->wave_log, c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
   for (void* b : bufs) if (b) (void)hipFree(b);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int k = 0; k < 2; k++) { if (c->pev0[k]) (void)hipEventDestroy(c->pev0[k]); if (c->pev1[k]) (void)hipEventDestroy(c->pev1[k]); }
-  for (int k = 1; k < dr_context::PIPE_STREAMS; k++) if (c->pipe_stream[k]) (void)hipStreamSynchronize(c->pipe_stream[k]);
-  if (c->acc_stream) (void)hipStreamSynchronize(c->acc_stream);
   for (int k = 0; k < dr_context::PIPE_DEPTH; k++) {
     if (c->pipe_frame[k]) (void)hipFree(c->pipe_frame[k]);
     if (c->pipe_rgb_dev[k]) (void)hipFree(c->pipe_rgb_dev[k]);
@@ -566,9 +478,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "feedback_every") *value = c->feedback_every;
   else if (n == "order_follows_camera") *value = c->order_follows_camera;
   else if (n == "occupancy") *value = c->occupancy;
-  else if (n == "trav_min") *value = c->trav_min;
-  else if (n == "park_min") *value = c->park_min;
-  else if (n == "unroll") *value = c->unroll;
+  else if (n == "schedule") *value = c->schedule;
   else if (n == "xcd_regions") *value = c->xcd_regions;
   else if (n == "heavy_factor") *value = c->heavy_factor;
   else if (n == "coop_steps") *value = c->coop_steps;
@@ -580,16 +490,8 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "split_steps") *value = c->split_steps;
   else if (n == "split_waves") *value = c->split_waves;
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
-  else if (n == "paired") *value = c->paired;
-  else if (n == "pool") *value = c->pool;
-  else if (n == "pool_shade_min") *value = c->pool_shade_min;
-  else if (n == "pool_diag") *value = c->pool_diag;
   else if (n == "pipe_streams") *value = c->pipe_streams;
   else if (n == "pipe_lean") *value = c->pipe_lean;
-  else if (n == "pool_shape") *value = c->pool_shape;
-  else if (n == "experimental") *value = experimental_built() ? 1 : 0;
-  else if (n == "roles") *value = c->roles;
-  else if (n == "pair_thresh") *value = c->pair_thresh;
   else if (n == "tree_depth") *value = c->tree_depth;
   else if (n == "wide_tree") *value = c->wide_tree;
   else if (n == "wide_depth") *value = c->wide ? c->wide_depth : 0;          // 0: the scene has no wide structure
@@ -711,7 +613,7 @@ int dr_render_accumulate(dr_context* c, const float settings13[13], int W, int H
   if (rc != DR_OK) return rc;
   if ((rc = collect_time(c, (uint64_t)nframes, samples)) != DR_OK) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return check_abort(c);
+  return DR_OK;
 }
 
 int dr_render_accumulate_async(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
@@ -736,7 +638,7 @@ int dr_context_synchronize(dr_context* c) {
   if ((rc = collect_pending(c, c->pending_next)) != DR_OK) return rc;       // older first
   if ((rc = collect_pending(c, c->pending_next ^ 1)) != DR_OK) return rc;
   HIP_TRY(hipStreamSynchronize(c->stream));
-  return check_abort(c);
+  return DR_OK;
 }
 
 int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed, int present_divide_by,
@@ -841,7 +743,7 @@ int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, 
 }
 
 int dr_pipeline_wait(dr_context* c, uint64_t ticket, uint8_t* out_rgb8) {
-  if (!c || !c->acc_stream) { set_error("pipeline: nothing submitted"); return DR_ERR_INVALID; }
+  if (!c || !c->pipe_ready) { set_error("pipeline: nothing submitted"); return DR_ERR_INVALID; }
   const uint64_t depth = (uint64_t)c->pipe_streams + 1;
   if (ticket >= c->pipe_next || ticket + depth < c->pipe_next) { set_error("pipeline: ticket not in flight (the pipeline keeps pipe_streams + 1 frames)"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
@@ -856,7 +758,7 @@ int dr_pipeline_wait(dr_context* c, uint64_t ticket, uint8_t* out_rgb8) {
 }
 
 int dr_pipeline_image(dr_context* c, uint64_t ticket, const uint8_t** rgb8) {
-  if (!c || !c->acc_stream || !rgb8) { set_error("pipeline: nothing submitted, or null argument"); return DR_ERR_INVALID; }
+  if (!c || !c->pipe_ready || !rgb8) { set_error("pipeline: nothing submitted, or null argument"); return DR_ERR_INVALID; }
   const uint64_t depth = (uint64_t)c->pipe_streams + 1;
   if (ticket >= c->pipe_next || ticket + depth < c->pipe_next) { set_error("pipeline: ticket not in flight (the pipeline keeps pipe_streams + 1 frames)"); return DR_ERR_INVALID; }
   const int slot = (int)(ticket % depth);
@@ -1001,33 +903,14 @@ int dr_stats_get(dr_context* c, dr_stats* out) {
   return DR_OK;
 }
 
-int dr_stats_kernel_diag(dr_context* c, unsigned long long* out, int n) {
-  if (!c || !out || n < 0 || n > COUNTER_WORDS - 16) { set_error("bad argument"); return DR_ERR_INVALID; }
-  HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (n > 0) HIP_TRY(hipMemcpy(out, c->counters + 16, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  return DR_OK;
-}
-
 int dr_stats_wave_log(dr_context* c, unsigned long long* out, int max_waves, int* n_waves) {
   if (!c || !out || !n_waves || max_waves < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
   if (!c->wave_log) { set_error("wave log is off (option wave_log)"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
   HIP_TRY(hipStreamSynchronize(c->stream));
   const int n = c->wave_log_waves < max_waves ? c->wave_log_waves : max_waves;
-  if (n > 0) HIP_TRY(hipMemcpy(out, c->wave_log, (size_t)n * COUNTER_WORDS * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  if (n > 0) HIP_TRY(hipMemcpy(out, c->wave_log, (size_t)n * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   *n_waves = n;
-  return DR_OK;
-}
-
-int dr_stats_pixel_times(dr_context* c, unsigned* out, size_t capacity, size_t* n) {
-  if (!c || !out || !n) { set_error("bad argument"); return DR_ERR_INVALID; }
-  HIP_TRY(hipSetDevice(c->device));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  size_t m = c->wave_log && c->pixel_cost ? (size_t)2 * c->order_capacity * 64 : 0;
-  if (m > PIXEL_LOG_WORDS || m > capacity) m = 0;
-  if (m > 0) HIP_TRY(hipMemcpy(out, c->wave_log + (size_t)WAVE_LOG_WAVES * 16, m * sizeof(unsigned), hipMemcpyDeviceToHost));
-  *n = m;
   return DR_OK;
 }
 

@@ -12,19 +12,6 @@
 #else
 #include <hip/hip_runtime.h>
 #endif
-// Sensitivity experiments (tools/exp_variant.sh): useless extra work in the wide walk's node step.  All 0 in the product.
-#ifndef DR_WAVE_LOG_DETAIL
-#define DR_WAVE_LOG_DETAIL 0  // experiment builds: the wave log (option wave_log) also counts phases, hand-overs and walking lanes of the drain
-#endif
-#ifndef DR_PAD_VALU
-#define DR_PAD_VALU 0      // n more VALU instructions per node step
-#endif
-#ifndef DR_MERGED_STEPS
-#define DR_MERGED_STEPS 1  // 1 (default): every step of an iteration takes leaf lanes along; 0: only the first (-0.7 % with park_min 8, -2.7 % with 16)
-#endif
-#ifndef DR_PAD_VMEM
-#define DR_PAD_VMEM 0      // n more 16-byte fetches per lane and node step, 64 B past the record each
-#endif
 #include <stdint.h>
 
 #include "device_layout.h"
@@ -113,20 +100,8 @@ struct Xorwow {
     const double d_hi = bits_double(0x45300000u, hi), d_lo = bits_double(0x43300000u, lo);
     return ((d_hi - 19342813118337666422669312.0) + d_lo) + 0.5;
   }
-#ifndef DR_UNIFORM_V2
-#define DR_UNIFORM_V2 1      // 0: the plain expressions (A/B builds)
-#endif
-#if DR_UNIFORM_V2
   __device__ __forceinline__ double uniform_double() { return z_plus_half() * 0x1p-53; }
   __device__ __forceinline__ float uniform_pm1() { return (float)__builtin_fma(z_plus_half(), 0x1p-52, -1.0); }      // (float)(uniform_double() * 2 - 1)
-#else
-  __device__ __forceinline__ double uniform_double() {
-    uint32_t x = next(), y = next();
-    uint64_t z = (uint64_t)x ^ ((uint64_t)y << 21);
-    return (double)z * 1.1102230246251565e-16 + 5.5511151231257827e-17;
-  }
-  __device__ __forceinline__ float uniform_pm1() { return (float)(uniform_double() * 2 - 1); }
-#endif
 };
 
 // The rejection test of K:645 / K:992 is pow(length(p), 2.0f) >= 1 with length = sqrtf(dot): l = RN(sqrt(d2)), then RN(l * l) >= 1.  Away from 1 the
@@ -134,9 +109,6 @@ struct Xorwow {
 // below 1; for d2 >= 1 + 2^-20, sqrt(d2) >= 1 + 2^-21 - 2^-43 rounds to at least 1 + 2^-21 and l * l > 1.  Only inside that band is the correctly
 // rounded square root (some fifteen instructions) really taken -- and the wave branches around it when none of its lanes is in the band.
 __device__ __forceinline__ bool outside_unit(float d2) {
-#if !DR_UNIFORM_V2
-  { const float l = __builtin_sqrtf(d2); return l * l >= 1; }
-#endif
   const bool band = __builtin_fabsf(d2 - 1.0f) < 0x1p-20f;
   bool out = d2 >= 1;
 #ifndef DR_HOST_BUILD
@@ -179,9 +151,6 @@ __device__ __forceinline__ V3 rand_in_unit_disk(Xorwow& r) {     // K:988-994
 // draws is exactly that of rand_in_unit_sphere / rand_in_unit_disk, but the wave runs the loop once, for as many turns as its unluckiest lane needs,
 // instead of once per kind (the persistent kernel's shade / refill phase: the lanes that scatter and the lanes that start a path).
 __device__ __forceinline__ V3 rand_points_merged(Xorwow& r, int kind) {
-#if !DR_UNIFORM_V2
-  return kind == 3 ? rand_in_unit_sphere(r) : (kind == 2 ? rand_in_unit_disk(r) : mk(0, 0, 0));
-#else
   V3 p = mk(0, 0, 0);
   bool todo = kind != 0;
   while (todo) {
@@ -197,7 +166,6 @@ __device__ __forceinline__ V3 rand_points_merged(Xorwow& r, int kind) {
     todo = outside_unit(dot(p, p));
   }
   return p;
-#endif
 }
 
 // ------------------------------------------------------------------ intersection
@@ -451,9 +419,6 @@ __device__ __forceinline__ void parked_test(V3 o, V3 d, Trav& tr, ParkedLeaf& pk
 // (equal t goes to the lower slot = the leaf the reference's walk reaches first).  Used only while a
 // launch drains (persistent kernel): idle lanes shorten the few long rays that set the launch time.
 constexpr int WAVE_LDS_DWORDS = 24 * 64;  // per-wave LDS region of the persistent kernel (6 KiB): phase stash / cooperative stack
-#ifndef DR_LDS_STACK
-#define DR_LDS_STACK WIDE_STACK      // stack words per lane the persistent kernel keeps in LDS.  Experiment builds (tools/exp_variant.sh -DDR_LDS_STACK=8 -DDR_LEAN_OCC=8)
-#endif                               // shrink it to make room for more waves per CU -- for TIMING only: deeper words are dropped there, frames are wrong
 constexpr int WIDE_STASH = 10;             // phase stash of the WIDE persistent kernel, dwords per lane (behind the WIDE_STACK stack words)
 constexpr int COOP_STACK = WAVE_LDS_DWORDS;   // node stack entries; a deeper frontier falls back to the plain walk
 
@@ -545,67 +510,43 @@ __device__ __forceinline__ bool coop_closest_hit(const DevPair* __restrict__ pai
 // register (`top`), older ones on a per-lane stack in LDS (word k of lane l at stack[k * 64 + l]: conflict-free).
 struct WideStack { unsigned top; int sp; int sb; };   // LDS words [sb, sp): sb > 0 once the oldest words have been handed to helper lanes
 
-__device__ __forceinline__ float ubyte_f(unsigned w, int k) { return (float)((w >> (8 * k)) & 255u); }   // v_cvt_f32_ubyte<k>
-
 // Tests the four children of a node; returns the mask of those the ray may enter no farther than best_t, and the key
 // of the nearest (entry distance bits with the child number in the two lowest bits).
 //
-// Arithmetic (DR_WIDE_FOLD, default): the ray is folded into the node's grid once per node -- a = scale * inv,
-// b = (origin - o) * inv -- and a plane costs one conversion and one fma: t = fma(byte, a, b -/+ m).  The result only
-// has to be CONSERVATIVE with respect to the slab test on the decoded plane p = fmaf(byte, scale, origin), which the
-// host checked to enclose the exact boxes: near planes not later, far planes not earlier than fl(fl(p - o) * inv).
-// Both computations differ from the real number (byte * scale + origin - o) * inv by at most
-//   |inv| * u * (3 P + 2 |o|)   [decode, subtract, multiply]   and   |inv| * u * (2 (P + |o|)) + u |t|   [this one],
-// u = 2^-24, P = the largest |plane coordinate| of the scene's nodes, so m = |inv| * 2^-21 * (P + |o|) covers the sum
-// with a quarter to spare (scale is a power of two in [2^-60, 2^60], so a is exact).
-// Extreme directions.  The folded test uses inv clamped to +-2^60 (WideRay::inv): for a zero direction component slab()
+// Arithmetic: the ray is folded into the node's grid once per node -- a = scale * inv, b = (origin - o) * inv -- and a plane
+// costs one fma: t = fma(byte, a, b -/+ m).  The result only has to be CONSERVATIVE with respect to the slab test on the
+// decoded plane p = fmaf(byte, scale, origin), which the host checked to enclose the exact boxes: near planes not later, far
+// planes not earlier than fl(fl(p - o) * inv).  Both computations differ from the real number (byte * scale + origin - o) * inv
+// by at most
+//   |inv| * u * (3 P + 2 |o|)   [decode, subtract, multiply]   and   u |inv| (3 |o| + P) + 2 u m + u |t|   [this one],
+// u = 2^-24, P = the largest |plane coordinate| of the scene's nodes; the sum is u |inv| (5 P + 6 |o|) + 3 u m < m =
+// 8 u |inv| (P + |o|) (scale is a power of two in [2^-60, 2^36], so a is exact; tools/study_wide_walk.cpp checks at every node of
+// every sample scene that this mask covers the decode-and-slab one).
+//  * a plane byte is read as the f16 DENORMAL byte * 2^-24 (half-word 0x00bb) and the node record stores scale * 2^24
+//    (device_layout.h), so that v_fma_mix_f32 converts the byte on the fly: fma(byte * 2^-24, (scale * 2^24) * inv, b) is the SAME
+//    real number rounded once as fma(byte, scale * inv, b) -- one instruction per plane instead of a conversion and an fma, and two
+//    plane bytes are unpacked by one v_and / v_perm (the kernel runs with f16 denormals on, .amdhsa_float_denorm_mode_16_64 3;
+//    dr_kat_node_planes checks the instruction).  Powers of two scale exactly as long as nothing overflows: |inv| <= 2^60
+//    (clamped), scale <= 2^36 (wide_builder.cpp refuses larger grids), so a <= 2^120.
+//  * b -/+ m = fma(origin, inv, -(fl(o * inv) +- m)) with the ray-only part precomputed by wide_ray().  o * inv could overflow
+//    for |o| > 2^67 where (origin - o) * inv did not: an axis with |o| >= 2^60 is left unconstrained (NaN margin).
+//  * the cap of the exit distance is the running best itself (trav_begin: "no hit yet" = 10000).
+// Extreme directions.  The test uses inv clamped to +-2^60 (WideRay::inv): for a zero direction component slab()
 // computes (p - o) * inf = +-inf, or NaN (ignored) when p == o; (p - o) * 2^60 -/+ m, with m >= 2^20 then, lands on
 // the same side of [0, 10000] for every plane at least m * 2^-60 away from the origin and leaves the nearer ones
 // unconstrained -- a superset again, and such rays (a few per frame: N + random can cancel exactly) are still culled
 // along that axis instead of walking the whole slab.  A NaN or > 2^60-long direction component makes m NaN: every plane of
 // that axis becomes NaN and is ignored by max3 / min3 (the axis is not constrained at all).
-// With DR_WIDE_FOLD 0 the planes are decoded and put through slab()'s own subtract-and-multiply (monotone, no margin).
-#ifndef DR_WIDE_FOLD
-#define DR_WIDE_FOLD 1
-#endif
-// DR_NODE_V2 (default, round 3): the same folded test, cheaper (with the sign words and the sign-based pass below: 539 -> 446 SIMD cycles per node step):
-//  * a plane byte is read as the f16 DENORMAL byte * 2^-24 (half-word 0x00bb) and the node record stores scale * 2^24 (device_layout.h), so that
-//    v_fma_mix_f32 converts the byte on the fly: fma(byte * 2^-24, (scale * 2^24) * inv, b) is the SAME real number rounded once as
-//    fma(byte, scale * inv, b) -- one instruction per plane instead of a conversion and an fma, and two plane bytes are unpacked by one
-//    v_and / v_perm (the kernel runs with f16 denormals on, .amdhsa_float_denorm_mode_16_64 3; dr_kat_node_planes checks the instruction).
-//    Powers of two scale exactly as long as nothing overflows: |inv| <= 2^60 (clamped), scale <= 2^36 (wide_builder.cpp refuses larger
-//    grids), so a <= 2^120.
-//  * b = fma(origin, inv, -(fl(o * inv) +- m)) with the ray-only part precomputed by wide_ray(): 6 instructions instead of 12.  Its error
-//    against the real (origin - o) * inv is u |inv| (3 |o| + P) + 2 u m (was 2 u |inv| (P + |o|)); with the plane's own u |t| and the
-//    decode-and-slab side's u |inv| (3 P + 2 |o|) the sum is u |inv| (5 P + 6 |o|) + 3 u m < m = 8 u |inv| (P + |o|): still covered.
-//    o * inv could overflow for |o| > 2^67 where (origin - o) * inv did not: an axis with |o| >= 2^60 is left unconstrained (NaN margin).
-//  * the cap of the exit distance is the running best itself (trav_begin: "no hit yet" = 10000).
-#ifndef DR_NODE_V2
-#define DR_NODE_V2 1
-#endif
-#ifndef DR_NODE_MIX
-#define DR_NODE_MIX 1        // planes through v_fma_mix_f32 (0: v_cvt_f32_ubyteN + v_fma_f32)
-#endif
-#ifndef DR_NODE_BFOLD
-#define DR_NODE_BFOLD 1      // 0: b = (origin - o) * inv -+ m as before (three registers fewer, six instructions more)
-#endif
-#if DR_NODE_V2 && DR_NODE_BFOLD
+// (The variants this replaced -- decode-and-slab, conversion + fma, compare + select -- are in the history of this file and
+// A/B-measured in profiles/r3_m_node_step_ab.txt.)
 struct WideRay { V3 inv, on, of; };      // inv: clamped 1/direction; on / of: fl(o * inv) + m, fl(o * inv) - m (what the near / far planes subtract)
-#else
-struct WideRay { V3 inv, marg; };        // what the folded node test needs of a ray besides its origin
-#endif
 __device__ __forceinline__ WideRay wide_ray_none() {      // a lane without a ray
   WideRay w;
-#if DR_NODE_V2 && DR_NODE_BFOLD
   w.inv = w.on = w.of = mk(0, 0, 0);
-#else
-  w.inv = w.marg = mk(0, 0, 0);
-#endif
   return w;
 }
 __device__ __forceinline__ WideRay wide_ray(V3 o, V3 inv, float pmax) {
   WideRay w;
-#if DR_NODE_V2 && DR_NODE_BFOLD
   auto one = [pmax](float oa, float ia, float& ic, float& on, float& of) {
     ic = __builtin_fminf(__builtin_fmaxf(ia, -0x1p60f), 0x1p60f);                    // NaN -> -2^60, and the margin below is NaN
     const float k = __builtin_fmaf(pmax + __builtin_fabsf(oa), 0x1p-21f, 0x1p-40f);
@@ -615,19 +556,9 @@ __device__ __forceinline__ WideRay wide_ray(V3 o, V3 inv, float pmax) {
     on = p + m; of = p - m;
   };
   one(o.x, inv.x, w.inv.x, w.on.x, w.of.x); one(o.y, inv.y, w.inv.y, w.on.y, w.of.y); one(o.z, inv.z, w.inv.z, w.on.z, w.of.z);
-#else
-  auto one = [pmax](float oa, float ia, float& ic, float& m) {
-    ic = __builtin_fminf(__builtin_fmaxf(ia, -0x1p60f), 0x1p60f);                    // NaN -> -2^60, and the margin below is NaN
-    const float k = __builtin_fmaf(pmax + __builtin_fabsf(oa), 0x1p-21f, 0x1p-40f);
-    const float ai = __builtin_fabsf(ic);
-    m = (ia == ia && ai > 0x1p-60f) ? ai * k : __builtin_nanf("");
-  };
-  one(o.x, inv.x, w.inv.x, w.marg.x); one(o.y, inv.y, w.inv.y, w.marg.y); one(o.z, inv.z, w.inv.z, w.marg.z);
-#endif
   return w;
 }
 
-#if DR_NODE_V2
 // The four plane bytes of a word as f16 denormals: (byte0, byte2) and (byte1, byte3), each pair in one register
 #ifdef DR_HOST_BUILD
 struct PlanePairs { unsigned even, odd; };
@@ -650,11 +581,7 @@ __device__ __forceinline__ float plane_t(const PlanePairs& p, int k, float a, fl
   return __builtin_fmaf((float)h, a, b);
 }
 #endif
-#endif
 
-#ifndef DR_NODE_SIGNPASS
-#define DR_NODE_SIGNPASS 1
-#endif
 // three-input bit operations (one v_bitop3_b32 each on the device; spelled out, the compiler re-associates them into slower pairs)
 #ifdef DR_HOST_BUILD
 __device__ __forceinline__ unsigned bit_select(unsigned if0, unsigned if1, unsigned m) { return (if0 & ~m) | (if1 & m); }
@@ -666,77 +593,29 @@ __device__ __forceinline__ unsigned bit_and_or(unsigned a, unsigned b, unsigned 
 __device__ __forceinline__ unsigned bit_andn(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x08); }
 #endif
 template <class Sign>
-__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, V3 o, V3 inv_plain, const WideRay& wr, const Sign& sg, float best_t, unsigned& near_key) {
+__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, const WideRay& wr, const Sign& sg, float best_t, unsigned& near_key) {
   const float ox = __uint_as_float(A.x), oy = __uint_as_float(A.y), oz = __uint_as_float(A.z);
   const float sx24 = __uint_as_float(B.x), sy24 = __uint_as_float(B.y), sz24 = __uint_as_float(B.z);      // scale * 2^24
-  const V3 inv = DR_WIDE_FOLD ? wr.inv : inv_plain;
+  const V3 inv = wr.inv;
   // the plane entered first is `hi` for a negative direction (slab(): same rule, so the comparison stays plane by plane)
   // (sg holds the signs of the plain 1/direction; the clamped one differs for a NaN only, and a NaN axis has NaN planes whichever word is read)
   const unsigned nxw = sg.sel(0, C.x, C.w), fxw = sg.sel(0, C.w, C.x);
   const unsigned nyw = sg.sel(1, C.y, D.x), fyw = sg.sel(1, D.x, C.y);
   const unsigned nzw = sg.sel(2, C.z, D.y), fzw = sg.sel(2, D.y, C.z);
-#if DR_NODE_SIGNPASS
   unsigned fail[4], kk[4];
-#else
-  unsigned mask = 0, key = 0xffffffffu;
-#endif
-#if DR_WIDE_FOLD && DR_NODE_V2
   const float tcap = best_t;
-#if DR_NODE_MIX
   const float ax = sx24 * inv.x, ay = sy24 * inv.y, az = sz24 * inv.z;
-#else
-  const float ax = (sx24 * 0x1p-24f) * inv.x, ay = (sy24 * 0x1p-24f) * inv.y, az = (sz24 * 0x1p-24f) * inv.z;
-#endif
-#if DR_NODE_BFOLD
-  (void)o;
   const float bxn = __builtin_fmaf(ox, inv.x, -wr.on.x), bxf = __builtin_fmaf(ox, inv.x, -wr.of.x);
   const float byn = __builtin_fmaf(oy, inv.y, -wr.on.y), byf = __builtin_fmaf(oy, inv.y, -wr.of.y);
   const float bzn = __builtin_fmaf(oz, inv.z, -wr.on.z), bzf = __builtin_fmaf(oz, inv.z, -wr.of.z);
-#else
-  const float bx = (ox - o.x) * inv.x, by = (oy - o.y) * inv.y, bz = (oz - o.z) * inv.z;
-  const float bxn = bx - wr.marg.x, bxf = bx + wr.marg.x, byn = by - wr.marg.y, byf = by + wr.marg.y, bzn = bz - wr.marg.z, bzf = bz + wr.marg.z;
-#endif
-#if DR_NODE_MIX
   const PlanePairs pnx = plane_pairs(nxw), pfx = plane_pairs(fxw), pny = plane_pairs(nyw), pfy = plane_pairs(fyw), pnz = plane_pairs(nzw), pfz = plane_pairs(fzw);
-#endif
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-#if DR_NODE_MIX
     const float t0x = plane_t(pnx, k, ax, bxn), t1x = plane_t(pfx, k, ax, bxf);
     const float t0y = plane_t(pny, k, ay, byn), t1y = plane_t(pfy, k, ay, byf);
     const float t0z = plane_t(pnz, k, az, bzn), t1z = plane_t(pfz, k, az, bzf);
-#else      // experiment: conversion (the "other" pipe) + plain fma (the fp32 pipe, which issues beside it) instead of v_fma_mix_f32 + unpacking
-    const float t0x = __builtin_fmaf(ubyte_f(nxw, k), ax, bxn), t1x = __builtin_fmaf(ubyte_f(fxw, k), ax, bxf);
-    const float t0y = __builtin_fmaf(ubyte_f(nyw, k), ay, byn), t1y = __builtin_fmaf(ubyte_f(fyw, k), ay, byf);
-    const float t0z = __builtin_fmaf(ubyte_f(nzw, k), az, bzn), t1z = __builtin_fmaf(ubyte_f(fzw, k), az, bzf);
-#endif
-#else
-  const float tcap = __builtin_fminf(best_t, 10000.0f);
-  const float sx = sx24 * 0x1p-24f, sy = sy24 * 0x1p-24f, sz = sz24 * 0x1p-24f;
-#if DR_WIDE_FOLD
-  const V3 marg = wr.marg;
-  const float ax = sx * inv.x, ay = sy * inv.y, az = sz * inv.z;
-  const float bx = (ox - o.x) * inv.x, by = (oy - o.y) * inv.y, bz = (oz - o.z) * inv.z;
-  const float bxn = bx - marg.x, bxf = bx + marg.x, byn = by - marg.y, byf = by + marg.y, bzn = bz - marg.z, bzf = bz + marg.z;
-#endif
-#pragma unroll
-  for (int k = 0; k < 4; k++) {
-#if DR_WIDE_FOLD
-    const float t0x = __builtin_fmaf(ubyte_f(nxw, k), ax, bxn), t1x = __builtin_fmaf(ubyte_f(fxw, k), ax, bxf);
-    const float t0y = __builtin_fmaf(ubyte_f(nyw, k), ay, byn), t1y = __builtin_fmaf(ubyte_f(fyw, k), ay, byf);
-    const float t0z = __builtin_fmaf(ubyte_f(nzw, k), az, bzn), t1z = __builtin_fmaf(ubyte_f(fzw, k), az, bzf);
-#else
-    const float nx = __builtin_fmaf(ubyte_f(nxw, k), sx, ox), fx = __builtin_fmaf(ubyte_f(fxw, k), sx, ox);
-    const float ny = __builtin_fmaf(ubyte_f(nyw, k), sy, oy), fy = __builtin_fmaf(ubyte_f(fyw, k), sy, oy);
-    const float nz = __builtin_fmaf(ubyte_f(nzw, k), sz, oz), fz = __builtin_fmaf(ubyte_f(fzw, k), sz, oz);
-    const float t0x = (nx - o.x) * inv.x, t1x = (fx - o.x) * inv.x;
-    const float t0y = (ny - o.y) * inv.y, t1y = (fy - o.y) * inv.y;
-    const float t0z = (nz - o.z) * inv.z, t1z = (fz - o.z) * inv.z;
-#endif
-#endif
     const float t_min = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(t0x, t0y), t0z), 0.0f);
     const float t_max = __builtin_fminf(__builtin_fminf(__builtin_fminf(t1x, t1y), t1z), tcap);
-#if DR_NODE_SIGNPASS
     // A child is entered when t_max >= t_min (>= where slab() has > and <=: a superset, which is all an internal node needs).  Taken from the SIGN
     // of t_max - t_min: neither is ever NaN (max / min ignore NaNs; 0 and the cap are numbers), t_max is finite or -inf, so the difference is a
     // number, +0 when they are equal.  (It is -0 only for t_max = -0, t_min = +0, where slab()'s own t_max > t_min fails anyway: still a superset.)
@@ -750,21 +629,11 @@ __device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u3
   // bit k of z = child k failed (the bits above are child 3's): three bitwise selects, then ~z & valid mask in one more
   const unsigned z = bit_select(bit_select(fail[3], fail[2], 4u), bit_select(fail[1], fail[0], 1u), 3u);      // bits 0-1 from the second, the rest from the first
   return bit_andn(z, B.w, 15u);
-#else
-    // >= where slab() has > and <=: a superset, which is all an internal node needs
-    const bool pass = t_max >= t_min;
-    mask |= pass ? (1u << k) : 0u;
-    const unsigned kk = pass ? ((__float_as_uint(t_min) & ~3u) | (unsigned)k) : 0xffffffffu;   // t_min >= 0: its bits order like the value
-    key = kk < key ? kk : key;
-  }
-  near_key = key;
-  return mask & (B.w & 15u);
-#endif
 }
 
-__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, V3 o, V3 inv_plain, const WideRay& wr, float best_t, unsigned& near_key) {
-  SignCmp sg; sg.inv = inv_plain;
-  return wide_node_test(A, B, C, D, o, inv_plain, wr, sg, best_t, near_key);
+__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, V3 inv_plain, const WideRay& wr, float best_t, unsigned& near_key) {
+  SignCmp sg; sg.inv = inv_plain;      // the planes chosen by comparing, as the reference does (per-tile kernel, host studies)
+  return wide_node_test(A, B, C, D, wr, sg, best_t, near_key);
 }
 
 // (t, slot) as one 64-bit key whose unsigned order is the lexicographic order of the pair (t is positive, or the 10000 of
@@ -792,11 +661,6 @@ __device__ __forceinline__ WideRec wide_fetch(WalkRsrc wide, int node) {
   const unsigned off = (unsigned)(node >> 1) << 6;
   WideRec r;
   r.A = ld_unit_raw(wide, off); r.B = ld_unit_raw(wide, off + 16); r.C = ld_unit_raw(wide, off + 32); r.D = ld_unit_raw(wide, off + 48);
-#if DR_PAD_VMEM
-  { u32x4 padm[DR_PAD_VMEM];
-    _Pragma("unroll") for (int k = 0; k < DR_PAD_VMEM; k++) padm[k] = ld_unit_raw(wide, off + 64u * (unsigned)(k + 1));
-    _Pragma("unroll") for (int k = 0; k < DR_PAD_VMEM; k++) asm volatile("" :: "v"(padm[k])); }
-#endif
 #ifndef DR_HOST_BUILD
   asm volatile("" : "+v"(r.A), "+v"(r.B), "+v"(r.C), "+v"(r.D));
 #endif
@@ -804,14 +668,11 @@ __device__ __forceinline__ WideRec wide_fetch(WalkRsrc wide, int node) {
 }
 
 template <bool COUNT, class Sign>
-__device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv, const WideRay& wr, const Sign& sg, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
+__device__ __forceinline__ void wide_node_compute(const WideRec& r, const WideRay& wr, const Sign& sg, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
   DR_MARK("node_begin");
   if (COUNT) c.V++;
-#if DR_PAD_VALU
-  _Pragma("unroll") for (int k = 0; k < DR_PAD_VALU; k++) asm volatile("v_or_b32 %0, 0, %0" : "+v"(tr.best_slot));
-#endif
   unsigned key;
-  const unsigned mask = wide_node_test(r.A, r.B, r.C, r.D, o, inv, wr, sg, tr.best_t, key);
+  const unsigned mask = wide_node_test(r.A, r.B, r.C, r.D, wr, sg, tr.best_t, key);
   if (mask != 0u) {
     // nearest entered child next; the others wait as one stack word.  An unused child slot (inverted box, valid bit
     // clear) can only pass on a degenerate grid or ray; if it even has the smallest key, take the lowest valid one.
@@ -820,7 +681,7 @@ __device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv
     const unsigned base = r.A.w & 0xffffffu, leafmask = (r.B.w >> 4) & 15u;
     const unsigned rest = mask & ~(1u << near);
     if (rest != 0u) {
-      if (ws.top != 0u) { if (ws.sp < DR_LDS_STACK) { stack[ws.sp * 64] = (int)ws.top; ws.sp++; } }   // the host bounds the depth; the guard only protects LDS
+      if (ws.top != 0u) { if (ws.sp < WIDE_STACK) { stack[ws.sp * 64] = (int)ws.top; ws.sp++; } }   // the host bounds the depth; the guard only protects LDS
       ws.top = (base << 8) | (leafmask << 4) | rest;
     }
     tr.node = (int)(((base + (unsigned)near) << 1) | ((leafmask >> near) & 1u));
@@ -830,7 +691,7 @@ __device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv
   DR_MARK("node_end");
 }
 
-template <bool COUNT, class Sign, bool POP = true>      // POP false: the lane moved on when it found this leaf (kernels_render.hip DR_LEAF_POSTPONE); only the test is left
+template <bool COUNT, class Sign>
 __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, V3 inv, const Sign& sg, Trav& tr, WideStack& ws, const int* __restrict__ stack, Ctr& c) {
   auto f = [](unsigned v) { return __uint_as_float(v); };
   DR_MARK("leaf_begin");
@@ -844,26 +705,20 @@ __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, 
     const int slot = info & ((1 << WALK_SLOT_BITS) - 1);
     if (t > 0.0f && (t < tr.best_t || (t == tr.best_t && (unsigned)slot < (unsigned)tr.best_slot))) { tr.best_t = t; tr.best_slot = slot; }
   }
-  if (POP) wide_pop(tr, ws, stack);
+  wide_pop(tr, ws, stack);
   DR_MARK("leaf_end");
 }
 
 template <bool COUNT>
-__device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 o, V3 inv, const WideRay& wr, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
+__device__ __forceinline__ void wide_node_compute(const WideRec& r, V3 inv, const WideRay& wr, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
   SignCmp sg; sg.inv = inv;
-  wide_node_compute<COUNT>(r, o, inv, wr, sg, tr, ws, stack, c);
+  wide_node_compute<COUNT>(r, wr, sg, tr, ws, stack, c);
 }
 template <bool COUNT>
 __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, V3 inv, Trav& tr, WideStack& ws, const int* __restrict__ stack, Ctr& c) {
   SignCmp sg; sg.inv = inv;
   wide_leaf_compute<COUNT>(r, o, d, inv, sg, tr, ws, stack, c);
 }
-template <bool COUNT>
-__device__ __forceinline__ void wide_node_step(WalkRsrc wide, V3 o, V3 inv, const WideRay& wr, Trav& tr, WideStack& ws, int* __restrict__ stack, Ctr& c) {
-  const WideRec r = wide_fetch(wide, tr.node);
-  wide_node_compute<COUNT>(r, o, inv, wr, tr, ws, stack, c);
-}
-
 template <bool COUNT>
 __device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, float pmax, V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [word * 64] */) {
   Trav tr;
@@ -875,7 +730,7 @@ __device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, float pmax, V3 o,
   while (tr.node >= 0) {
     const WideRec r = wide_fetch(wide, tr.node);
     if (tr.node & 1) wide_leaf_compute<COUNT>(r, o, d, inv, tr, ws, stack, c);
-    else wide_node_compute<COUNT>(r, o, inv, wr, tr, ws, stack, c);
+    else wide_node_compute<COUNT>(r, inv, wr, tr, ws, stack, c);
   }
   Hit best; best.t = tr.best_slot < 0 ? -1.0f : tr.best_t; best.slot = tr.best_slot;
   return best;

@@ -216,18 +216,12 @@ __global__ void kat_aabb_kernel(int n, const float* o, const float* d, const flo
 __global__ void kat_node_planes_kernel(int n, const uint32_t* w, const float* a, const float* b, float* t_mix, float* t_cvt) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-#if DR_NODE_V2
   const PlanePairs p = plane_pairs(w[i]);
   const float a24 = a[i] * 0x1p24f;
-#endif
 #pragma unroll
   for (int k = 0; k < 4; k++) {
-#if DR_NODE_V2
-    t_mix[4 * i + k] = plane_t(p, k, a24, b[i]);
-#else
-    t_mix[4 * i + k] = __builtin_fmaf(ubyte_f(w[i], k), a[i], b[i]);
-#endif
-    t_cvt[4 * i + k] = __builtin_fmaf(ubyte_f(w[i], k), a[i], b[i]);
+    t_mix[4 * i + k] = plane_t(p, k, a24, b[i]);                                                         // the kernel's instruction (v_fma_mix_f32 on the f16 denormal)
+    t_cvt[4 * i + k] = __builtin_fmaf((float)((w[i] >> (8 * k)) & 255u), a[i], b[i]);                    // conversion + fma
   }
 }
 __global__ void kat_tri_kernel(int n, const float* o, const float* d, const float* v0, const float* v1, const float* v2, float* t) {

@@ -72,24 +72,6 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // code in the loop, so launches whose queue is long enough to hide their tail use the lean build (80 VGPRs and 26 KiB of LDS at
 // OCC = 6: six waves per SIMD; launch_persistent / launch_wide_lean6 pick).
 
-#ifndef DR_LEAF_IF_MORE
-#define DR_LEAF_IF_MORE 0
-#endif
-#ifndef DR_PHASE_HOME
-#define DR_PHASE_HOME (!DR_WAVE_LOG_DETAIL)           // wide walk: colour, pixel, sample and frame live in the phase stash outside the phase (0: in registers, as before)
-#endif
-#ifndef DR_MERGED_DRAWS
-#define DR_MERGED_DRAWS 1         // one rejection loop per shade / refill phase for sphere and disk points together (0: one each, as before)
-#endif
-#ifndef DR_LEAF_POSTPONE
-#define DR_LEAF_POSTPONE 0        // lean build: a lane that reaches a leaf keeps it pending and goes on with node steps (speculative: its bound is stale until the leaf is tested)
-#endif
-#ifndef DR_SIGN_MASKS
-#define DR_SIGN_MASKS 1           // wide walk: near / far planes selected with per-lane sign words and v_bitop3 (device_core.hpp SignMask; 0: compare + v_cndmask per step)
-#endif
-#ifndef DR_EXCLUSIVE_STEPS
-#define DR_EXCLUSIVE_STEPS 1      // wide walk: an iteration's step is a leaf step OR a node step (0: both kinds of lanes step together, as in round 2)
-#endif
 template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE, bool COOP = true>
 __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, const int* __restrict__ region_start,
@@ -105,15 +87,15 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   //    the wide walk's work sharing.  The wide walk's own stack (WIDE_STACK words per lane) sits in front of the stash.
   // WIDE && COOP: three more words per lane behind the stash -- the shared best hit (64-bit key) and the number of helper lanes of
   // a ray whose subtrees have been handed out (drain phase, below)
-  constexpr int SHARE_OFF = (DR_LDS_STACK + WIDE_STASH) * 64;
-  constexpr int REGION = WIDE ? (DR_LDS_STACK + WIDE_STASH + (COOP ? 3 : 0)) * 64 : WAVE_LDS_DWORDS;
+  constexpr int SHARE_OFF = (WIDE_STACK + WIDE_STASH) * 64;
+  constexpr int REGION = WIDE ? (WIDE_STACK + WIDE_STASH + (COOP ? 3 : 0)) * 64 : WAVE_LDS_DWORDS;
   __shared__ __attribute__((aligned(16))) int wave_lds[4 * REGION];
   int* const my_lds = wave_lds + (threadIdx.x >> 6) * REGION;
   int* const my_stack = my_lds + lane;                             // WIDE: word k of this lane's stack at my_stack[k * 64]
   unsigned long long* const share_key = reinterpret_cast<unsigned long long*>(my_lds + (WIDE ? SHARE_OFF : 0));     // [64], WIDE && COOP only
   unsigned* const share_pend = reinterpret_cast<unsigned*>(my_lds + (WIDE ? SHARE_OFF : 0) + 128);                   // [64]
-  if (WIDE && DR_PHASE_HOME) {     // the phase-only state lives in the stash (see the phase): no pixel yet
-    int* const st0 = my_lds + DR_LDS_STACK * 64 + lane;
+  if (WIDE) {                      // the phase-only state lives in the stash (see the phase): no pixel yet
+    int* const st0 = my_lds + WIDE_STACK * 64 + lane;
     for (int k = 1; k < 8; k++) st0[k * 64] = 0;
   }
   int share = -1;                  // -1: this lane walks a ray of its own, alone; 0..63: it helps that lane's ray; 64: its ray has helpers
@@ -149,11 +131,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   Path path; path.rayo = mk(0, 0, 0); path.raydir = mk(0, 0, 0); path.atten = mk(0, 0, 0);
   V3 inv = mk(0, 0, 0), color = mk(0, 0, 0);
   WideRay wr = wide_ray_none();    // WIDE: clamped 1/direction and margins of the folded node test, a function of the lane's ray
-#if DR_SIGN_MASKS
   SignMask sg = sign_mask(inv);    // ... and the signs of 1/direction as select masks
-#else
-  SignCmp sg; sg.inv = inv;
-#endif
   Xorwow rng; rng.v0 = rng.v1 = rng.v2 = rng.v3 = rng.v4 = rng.d = 0;
   int px = -1, py = 0, sample = 0, bounce = 0;
   int frame = 0;                   // frame of the batch the pixel in this slot belongs to
@@ -170,23 +148,14 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
   bool held = false;               // COOP: this wave has pixels of a split tile and fetches no new tiles while they live
   // wave log (option wave_log): when this wave first found the queue empty, loop iterations since.  Only in the build that short launches
   // use (their timeline is what the log is for): the two scalar instructions per iteration cost the long launches 0.5 %
-  constexpr bool WAVE_LOG = (WIDE && COOP) || DR_WAVE_LOG_DETAIL;
+  constexpr bool WAVE_LOG = WIDE && COOP;
   unsigned long long r_empty = 0, n_after = 0;
-  unsigned long long d_iters = 0;      // loop iterations of the wave
-  unsigned long long d_home_tiles = 0, d_stolen_tiles = 0, d_left_home = 0;      // (tools/exp_regions.py) tiles from the region the wave began in / from others, when it left the first
-  const int d_home = region;
-  unsigned long long d_want_give = 0, d_idle = 0, d_owner_walk = 0, d_share_iters = 0, d_wait_owner = 0, d_pending = 0;   // ... of the iterations in which the sharing block ran: givers, idle lanes, walking owners, owners waiting for helpers, lanes waiting for a phase
-  unsigned long long d_phases = 0, d_given = 0, d_walking = 0, d_phase_ticks = 0;      // -DDR_WAVE_LOG_DETAIL builds: phases, hand-overs, walking lanes summed, ticks inside phases, all after the queue ran empty
-  constexpr bool POSTPONE = WIDE && !COOP && DR_LEAF_POSTPONE;
-  int pend = -1;                   // POSTPONE: the leaf (record << 1 | 1) this lane has found and not yet tested
   ParkedLeaf pk; pk.v0x = 0; pk.C = pk.D = u32x4{0, 0, 0, 0}; pk.info = 0; pk.parked = false;   // PARK_MIN > 0 only
   for (;;) {
     DR_MARK("loop_top");
-    const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked) || (POSTPONE && pend >= 0));
+    const unsigned long long walking = __ballot(tr.node >= 0 || (PARK_MIN > 0 && pk.parked));
     if (COUNT) n_iter++;
     if (WAVE_LOG && r_empty != 0ull) n_after++;
-    if (DR_WAVE_LOG_DETAIL) d_iters++;
-    if (DR_WAVE_LOG_DETAIL && r_empty != 0ull) d_walking += (unsigned long long)__popcll(__ballot(tr.node >= 0));
     // (a wave that only drains -- queue empty, nobody waiting to be shaded or refilled -- skips the phase: its stash/restore would be
     // paid on every iteration of the launch's tail)
     if (WIDE && COOP) {
@@ -211,38 +180,24 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
     }
     const bool waits_for_helpers = WIDE && COOP && share == 64;      // (only ever true with tr.node == -1 here or while still walking)
     // (a holding wave -- long pixels, helpers walking for them -- shades as soon as a ray is finished: its pixels' latency is the point)
-#ifdef DR_TRAV_THR
-    constexpr int trav_thr = DR_TRAV_THR;            // experiment builds
-#else
-    constexpr int trav_thr = TRAV_MIN;
-#endif
-    if ((__popcll(walking) < trav_thr || (WIDE && COOP && held)) && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers && !(POSTPONE && pend >= 0)) || tr.node == -2) != 0ull)) {
+    if ((__popcll(walking) < TRAV_MIN || (WIDE && COOP && held)) && (walking == 0ull || __ballot((tr.node == -1 && !waits_for_helpers) || tr.node == -2) != 0ull)) {
       unsigned long long t0 = 0;
       DR_MARK("phase_begin");
       if (COUNT) { t0 = __builtin_readcyclecounter(); n_phase++; }
-      unsigned long long d_t0 = 0;
-      if (DR_WAVE_LOG_DETAIL && r_empty != 0ull) { d_phases++; d_t0 = __builtin_amdgcn_s_memrealtime(); }
-      const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked) && !waits_for_helpers && !(POSTPONE && pend >= 0);
+      const bool shade_me = tr.node == -1 && !(PARK_MIN > 0 && pk.parked) && !waits_for_helpers;
       if (COUNT) n_shaded += __popcll(__ballot(shade_me));
       bool fresh_ray = false;                  // this lane starts a new ray in this phase: 1/direction is recomputed after the phase
-      constexpr bool BOUNCE_HOME = WIDE && !COOP && DR_PHASE_HOME;      // lean build: the bounce count lives in stash word 9 (one register more for the walk)
-      float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? DR_LDS_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
+      constexpr bool BOUNCE_HOME = WIDE && !COOP;      // lean build: the bounce count lives in stash word 9 (one register more for the walk)
+      float* const st = reinterpret_cast<float*>(my_lds) + (WIDE ? WIDE_STACK * 64 : 0) + lane;      // slot k of this lane: st[k * 64]
       if (WIDE) {
         // ten words (26 KiB of LDS per workgroup with the stack: six workgroups per CU).  Words 2-7 (colour, x + 1 (0: no pixel) with y -- make_params
         // bounds the frame size --, pixel code, sample) and the frame of the batch (upper half of word 1) are needed in this phase only: they LIVE
-        // here and are registers only between the read after shading and the write at the end of the phase (DR_PHASE_HOME; the walk loop has
-        // eight registers more for the node step).  What goes in now is the walk's state: stack top, stack pointer, step counts.
+        // here and are registers only between the read after shading and the write at the end of the phase (the walk loop has eight registers
+        // more for the node step).  What goes in now is the walk's state: stack top, stack pointer, step counts.
         st[0 * 64] = __uint_as_float(ws.top);
-#if DR_PHASE_HOME
         reinterpret_cast<unsigned char*>(st + 1 * 64)[0] = (unsigned char)ws.sp;
-#else
-        st[1 * 64] = __int_as_float(ws.sp | (frame << 16));
-        st[2 * 64] = color.x; st[3 * 64] = color.y; st[4 * 64] = color.z;
-        st[5 * 64] = __int_as_float(((px + 1) << 16) | py); st[6 * 64] = __int_as_float(pcode);
-        st[7 * 64] = __int_as_float(sample);
-#endif
         st[8 * 64] = __uint_as_float(steps);
-        if (COOP || !DR_PHASE_HOME) st[9 * 64] = __uint_as_float(rstart);      // (lean build: the ray's first step is of no use to it, and word 9 is where `bounce` lives)
+        if (COOP) st[9 * 64] = __uint_as_float(rstart);      // (lean build: the ray's first step is of no use to it, and word 9 is where `bounce` lives)
         asm volatile("" ::: "memory");
       } else {
         st[0 * 64] = pk.v0x; st[1 * 64] = __uint_as_float(pk.C.x); st[2 * 64] = __uint_as_float(pk.C.y); st[3 * 64] = __uint_as_float(pk.C.z); st[4 * 64] = __uint_as_float(pk.C.w);
@@ -260,7 +215,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       DR_MARK("phase_shade");
       bool ended = false;
       V3 radiance = mk(0, 0, 0);
-      // (DR_MERGED_DRAWS: the hit is shaded in two parts around the phase's ONE rejection loop, which serves the lanes that scatter -- a point in the unit
+      // (the hit is shaded in two parts around the phase's ONE rejection loop, which serves the lanes that scatter -- a point in the unit
       // sphere -- and, further down, the lanes that start a path -- a point in the unit disk: device_core.hpp rand_points_merged.  A path that ends
       // here, at an emissive surface or at the depth limit, draws nothing more: its generator is re-seeded with its next pixel.)
       ShadeCtx sc; sc.hitpoint = sc.N = sc.ocolor = mk(0, 0, 0); sc.add_x = sc.rough = sc.ir = sc.r5 = 0.0f; sc.mat = -1; sc.front = false;
@@ -275,9 +230,6 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
             else scatter_me = true;
             if (BOUNCE_HOME) st[9 * 64] = __int_as_float(bounce);
           }
-#if !DR_MERGED_DRAWS
-          if (scatter_me) { shade_scatter(path, sc, shade_needs_sphere(sc) ? rand_in_unit_sphere(rng) : mk(0, 0, 0), rng); scatter_me = false; }
-#endif
         } else {
           radiance = shade_miss<COUNT>(P, path, c);
           ended = true;
@@ -291,7 +243,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         pcode = __float_as_int(st[6 * 64]);
         frame = (int)((unsigned)__float_as_int(st[1 * 64]) >> 16); sample = __float_as_int(st[7 * 64]);
         steps = __float_as_uint(st[8 * 64]);
-        if (COOP || !DR_PHASE_HOME) rstart = __float_as_uint(st[9 * 64]);
+        if (COOP) rstart = __float_as_uint(st[9 * 64]);
       } else {
         asm volatile("" ::: "memory");
         color = mk(st[14 * 64], st[15 * 64], st[16 * 64]);
@@ -320,8 +272,6 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           if (px >= 0) {
             store_pixel(P, px, py, color);
             if (pixel_cost) pixel_cost[pcode & 0x7fffffff] = steps;
-            if (DR_WAVE_LOG_DETAIL && P.wave_log)      // experiment builds: when the pixel was finished (100 MHz ticks since the wave began, i.e. since the launch)
-              reinterpret_cast<unsigned*>(P.wave_log + (size_t)WAVE_LOG_WAVES * 16)[(size_t)ntiles * 64 + (pcode & 0x7fffffff)] = (unsigned)(__builtin_amdgcn_s_memrealtime() - r_begin);
           }
           px = -1;
           want_pixel = true;
@@ -364,10 +314,8 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
                 tt -= nsplit * (P.split_parts - 1);
               }
               cur_tile = tile_order ? tile_order[r0 + tt] : r0 + tt;
-              if (DR_WAVE_LOG_DETAIL) { if (region == d_home) d_home_tiles++; else d_stolen_tiles++; }
               break;
             }
-            if (DR_WAVE_LOG_DETAIL && region == d_home && d_left_home == 0ull) d_left_home = __builtin_amdgcn_s_memrealtime();
             region = region + 1 == P.regions ? 0 : region + 1;   // this band is done: help with the next one
             regions_left--;
           }
@@ -390,8 +338,6 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           sample = 0;
           color = mk(0, 0, 0);
           want_pixel = false;
-          if (DR_WAVE_LOG_DETAIL && P.wave_log)        // ... and when it was started
-            reinterpret_cast<unsigned*>(P.wave_log + (size_t)WAVE_LOG_WAVES * 16)[pcode & 0x7fffffff] = (unsigned)(__builtin_amdgcn_s_memrealtime() - r_begin);
         }
         const int n = __popcll(need);
         cur_next += n < avail ? n : avail;
@@ -414,11 +360,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
       {
         // ---- the phase's rejection loop, once for the wave: sphere points for the lanes that scatter, disk points for the lanes that start a path
-#if DR_MERGED_DRAWS
         const V3 pt = rand_points_merged(rng, scatter_me && shade_needs_sphere(sc) ? 3 : (new_path ? 2 : 0));
-#else
-        const V3 pt = new_path ? rand_in_unit_disk(rng) : mk(0, 0, 0);
-#endif
         if (scatter_me) shade_scatter(path, sc, pt, rng);
         if (new_path) {
           camera_finish(P, cam_nu, cam_nv, pt, path.rayo, path.raydir);
@@ -434,7 +376,6 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       if (WIDE) {
         asm volatile("" ::: "memory");
         ws.top = __float_as_uint(st[0 * 64]); ws.sp = __float_as_int(st[1 * 64]) & 0xff;
-#if DR_PHASE_HOME
         // the phase-only state goes home (the values in registers are dead from here to the next phase)
         st[2 * 64] = color.x; st[3 * 64] = color.y; st[4 * 64] = color.z;
         st[5 * 64] = __int_as_float(((px + 1) << 16) | py); st[6 * 64] = __int_as_float(pcode);
@@ -442,15 +383,10 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         reinterpret_cast<unsigned short*>(st + 1 * 64)[1] = (unsigned short)frame;
         asm volatile("" ::: "memory");
         color = mk(0, 0, 0); px = -1; py = 0; pcode = 0; sample = 0; frame = 0;
-#endif
         if (fresh_ray) { ws.top = 0u; ws.sp = 0; ws.sb = 0; }
         inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);      // 1/direction and the folded test's margins are
         wr = wide_ray(path.rayo, inv, P.wide_pmax);                                        // recomputed for every lane rather than stashed
-#if DR_SIGN_MASKS
         sg = sign_mask(inv);
-#else
-        sg.inv = inv;
-#endif
       } else {
         asm volatile("" ::: "memory");
         pk.v0x = st[0 * 64]; pk.C = u32x4{__float_as_uint(st[1 * 64]), __float_as_uint(st[2 * 64]), __float_as_uint(st[3 * 64]), __float_as_uint(st[4 * 64])};
@@ -460,7 +396,6 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         if (fresh_ray) inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
       }
       if (COUNT) t_phase += __builtin_readcyclecounter() - t0;
-      if (DR_WAVE_LOG_DETAIL && d_t0 != 0ull) d_phase_ticks += __builtin_amdgcn_s_memrealtime() - d_t0;
       DR_MARK("phase_end");
       if (__ballot(tr.node != -3) == 0ull) break;
     }
@@ -479,19 +414,12 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       const int n_idle = (int)__popcll(idle), n_give = (int)__popcll(givers);
       // (with the phase-only state at home in stash words 1-7, the exchange has words 8-9 of the stash -- the step counts, in registers
       // between phases -- to itself: 128 words = 16 hand-overs of 8 words per round)
-      constexpr int XCH_MAX = DR_PHASE_HOME ? 16 : 64;
+      constexpr int XCH_MAX = 16;
       const int n_most = n_idle < n_give ? n_idle : n_give;
       const int n = n_most < XCH_MAX ? n_most : XCH_MAX;
-      if (DR_WAVE_LOG_DETAIL && round == 0) {
-        d_share_iters++; d_want_give += (unsigned long long)n_give; d_idle += (unsigned long long)n_idle;
-        d_owner_walk += (unsigned long long)__popcll(__ballot(tr.node >= 0 && px >= 0));
-        d_wait_owner += (unsigned long long)__popcll(__ballot(tr.node == -1 && share == 64));
-        d_pending += (unsigned long long)__popcll(__ballot((tr.node == -1 && share != 64) || tr.node == -2));
-      }
       if (n == 0) break;
       {
-        if (DR_WAVE_LOG_DETAIL) d_given += (unsigned long long)n;
-        int* const xch = my_lds + (DR_LDS_STACK + (DR_PHASE_HOME ? 8 : 0)) * 64;      // field f of hand-over e at xch[f * XCH_MAX + e]
+        int* const xch = my_lds + (WIDE_STACK + 8) * 64;      // field f of hand-over e at xch[f * XCH_MAX + e]
         const int rank_g = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(givers >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)givers, 0u));
         const int rank_i = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
         if (can_give && rank_g < n) {
@@ -515,11 +443,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           share = xch[rank_i + 7 * XCH_MAX];
           inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
           wr = wide_ray(path.rayo, inv, P.wide_pmax);
-#if DR_SIGN_MASKS
           sg = sign_mask(inv);
-#else
-          sg.inv = inv;
-#endif
           const unsigned long long k = share_key[share];
           tr.best_t = __uint_as_float((unsigned)(k >> 32)); tr.best_slot = (int)(unsigned)k;
           wide_pop(tr, ws, my_stack);                              // the first pending child of the word
@@ -554,101 +478,33 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         }
       }
     }
-    if (POSTPONE) {
-      // ---- leaf postponing: a lane that reaches a leaf takes it along (`pend`) and goes on with the next record of its stack; it stands still only
-      // with a SECOND leaf in hand.  Node steps run for the lanes that would otherwise wait at a leaf; what they visit with a bound that does not
-      // know the pending leaf's hit yet is a superset, and the result -- the lexicographic minimum over the leaves tested -- is the same.
-#ifdef DR_PARK_THR
-      constexpr int park_thr = DR_PARK_THR;
-#else
-      constexpr int park_thr = PARK_MIN > 0 ? PARK_MIN : 1;
-#endif
-      const bool draining = cur_tile >= ntiles;
-      for (int u = 0; u < P_UNROLL; u++) {
-        if (tr.node >= 0 && (tr.node & 1) && pend < 0) { pend = tr.node; wide_pop(tr, ws, my_stack); }
-        const bool has_leaf = pend >= 0, at_node = tr.node >= 0 && !(tr.node & 1);
-        const unsigned long long leaves = __ballot(has_leaf), nodes = __ballot(at_node);
-        const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= park_thr || nodes == 0ull || draining);
-        if (COUNT) { n_leafstep += do_leaves; n_nodestep += nodes != 0ull && !do_leaves; }
-        if (do_leaves) {
-          if (has_leaf) {
-            const WideRec r = wide_fetch(walk, pend);
-            wide_leaf_compute<COUNT, decltype(sg), false>(r, path.rayo, path.raydir, inv, sg, tr, ws, my_stack, c);
-            pend = -1;
-            steps++;
-          }
-        } else if (at_node) {
-          const WideRec r = wide_fetch(walk, tr.node);
-          wide_node_compute<COUNT>(r, path.rayo, inv, wr, sg, tr, ws, my_stack, c);
-          steps++;
-        }
-      }
-    } else if (WIDE) {
+    if (WIDE) {
       // ---- one record per walking lane.  Lanes at a leaf (exact box + primitive: the long block) wait until enough of
-      // them stand at one, or nobody can take a node step; when they go, they fetch together with the lanes at nodes, so
-      // the wave waits for one round trip, not two.
-      const bool at_leaf = tr.node >= 0 && (tr.node & 1);
-      const unsigned long long leaves = __ballot(at_leaf);
-      const unsigned long long nodes = __ballot(tr.node >= 0 && !(tr.node & 1));
+      // them stand at one, or nobody can take a node step.
       // A leaf step and a node step taken together share their fetch round trip, but each then runs for about half the wave (the two are
       // different code).  The kernel is bound by instruction issue, not by latency (seven waves per SIMD are no faster than six,
-      // profiles/r3_h), so outside the drain the node lanes sit out a leaf step and the node steps in between run fuller:
-      // 0.626 -> 0.598 ms/frame with park_min 20 (profiles/r3_i_exclusive_steps.txt; DR_EXCLUSIVE_STEPS 0 = round 2's merged steps).
-#ifdef DR_PARK_THR
-      constexpr int park_thr = DR_PARK_THR;            // experiment builds
-#else
+      // profiles/r3_h), so outside the drain the node lanes of the lean build sit out a leaf step and the node steps in between run fuller:
+      // 0.626 -> 0.598 ms/frame with park_min 20 (profiles/r3_i_exclusive_steps.txt).  The work-sharing build keeps the merged steps (one
+      // round trip for both kinds of lanes): what exclusive steps gain in its bulk they lose in its tail, 1.10 against 1.075 ms for a single frame.
+      // (Leaf postponing, "leaves as soon as they outnumber the nodes" and other thresholds: measured and dropped, profiles/r3_t_*, r3_p_*.)
       constexpr int park_thr = PARK_MIN > 0 ? PARK_MIN : 1;
-#endif
+      constexpr bool EXCLUSIVE = !COOP;
       const bool draining = cur_tile >= ntiles || held;
-#if DR_LEAF_IF_MORE      // experiment: ... or as soon as more lanes stand at leaves than at nodes
-      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= park_thr || __popcll(leaves) >= __popcll(nodes) + DR_LEAF_IF_MORE - 1 || draining);
-#else
-      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= park_thr || nodes == 0ull || draining);
-#endif
-      // (not in the work-sharing build of short launches: what it gains in their bulk it loses in their tail, 1.10 against 1.075 ms for a single frame)
-#ifndef DR_EXCLUSIVE_COOP
-#define DR_EXCLUSIVE_COOP 0       // (experiment builds: exclusive steps in the work-sharing build's bulk too)
-#endif
-      constexpr bool EXCLUSIVE = DR_EXCLUSIVE_STEPS && (!COOP || DR_EXCLUSIVE_COOP);
-      const bool do_nodes = !EXCLUSIVE || !do_leaves || draining;
-      if (COUNT) { n_leafstep += do_leaves; n_nodestep += nodes != 0ull && do_nodes; }
-      if (tr.node >= 0 && (at_leaf ? do_leaves : do_nodes)) {
-        if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
-        const WideRec r = wide_fetch(walk, tr.node);
-        if (at_leaf) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, sg, tr, ws, my_stack, c);
-        else wide_node_compute<COUNT>(r, path.rayo, inv, wr, sg, tr, ws, my_stack, c);
-        steps++;
-      }
-#if DR_MERGED_STEPS
-      for (int u = 1; u < P_UNROLL; u++) {         // the further steps of an iteration take leaf lanes along too
-        const bool at_leaf2 = tr.node >= 0 && (tr.node & 1);
-        const unsigned long long leaves2 = __ballot(at_leaf2);
-        const unsigned long long nodes2 = __ballot(tr.node >= 0 && !(tr.node & 1));
-#if DR_LEAF_IF_MORE
-        const bool do_leaves2 = leaves2 != 0ull && ((int)__popcll(leaves2) >= park_thr || __popcll(leaves2) >= __popcll(nodes2) + DR_LEAF_IF_MORE - 1 || draining);
-#else
-        const bool do_leaves2 = leaves2 != 0ull && ((int)__popcll(leaves2) >= park_thr || nodes2 == 0ull || draining);
-#endif
-        const bool do_nodes2 = !EXCLUSIVE || !do_leaves2 || draining;
-        if (COUNT) { n_leafstep += do_leaves2; n_nodestep += nodes2 != 0ull && do_nodes2; }
-        if (tr.node >= 0 && (at_leaf2 ? do_leaves2 : do_nodes2)) {
+      for (int u = 0; u < P_UNROLL; u++) {         // every step of an iteration decides anew
+        const bool at_leaf = tr.node >= 0 && (tr.node & 1);
+        const unsigned long long leaves = __ballot(at_leaf);
+        const unsigned long long nodes = __ballot(tr.node >= 0 && !(tr.node & 1));
+        const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= park_thr || nodes == 0ull || draining);
+        const bool do_nodes = !EXCLUSIVE || !do_leaves || draining;
+        if (COUNT) { n_leafstep += do_leaves; n_nodestep += nodes != 0ull && do_nodes; }
+        if (tr.node >= 0 && (at_leaf ? do_leaves : do_nodes)) {
           if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
           const WideRec r = wide_fetch(walk, tr.node);
-          if (at_leaf2) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, sg, tr, ws, my_stack, c);
-          else wide_node_compute<COUNT>(r, path.rayo, inv, wr, sg, tr, ws, my_stack, c);
+          if (at_leaf) wide_leaf_compute<COUNT>(r, path.rayo, path.raydir, inv, sg, tr, ws, my_stack, c);
+          else wide_node_compute<COUNT>(r, wr, sg, tr, ws, my_stack, c);
           steps++;
         }
       }
-#else
-      for (int u = 1; u < P_UNROLL; u++) {
-        if (COUNT) n_nodestep += __ballot(tr.node >= 0 && !(tr.node & 1)) != 0ull;
-        if (tr.node >= 0 && !(tr.node & 1)) {
-          if (COUNT) { if (first_active_lane()) c.trav_slots += 64; }
-          wide_node_step<COUNT>(walk, path.rayo, inv, wr, tr, ws, my_stack, c);
-          steps++;
-        }
-      }
-#endif
     } else if (PARK_MIN > 0) {
       // ---- test the parked leaves once enough lanes hold one (or nobody could step anyway)
       const unsigned long long parked = __ballot(pk.parked);
@@ -681,9 +537,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
     atomicAdd(&P.counters[15], r_end - r_begin);      // 100 MHz ticks: wave cycles / this = shader clock / 100 MHz
     if (WAVE_LOG && P.wave_log) {
       unsigned long long* const w = P.wave_log + (size_t)wave_id * 16;
-      w[0] = r_begin; w[1] = r_empty; w[2] = r_end; w[3] = n_after; w[4] = d_phases; w[5] = d_given; w[6] = d_walking; w[7] = d_phase_ticks;
-      w[8] = d_want_give; w[9] = d_idle; w[10] = d_owner_walk; w[11] = d_share_iters; w[12] = d_wait_owner; w[13] = d_pending; w[14] = d_iters;
-      if (DR_WAVE_LOG_DETAIL) { w[4] = d_home_tiles; w[5] = d_stolen_tiles; w[6] = d_left_home; w[15] = (unsigned long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u); }
+      w[0] = r_begin; w[1] = r_empty; w[2] = r_end; w[3] = n_after;
     }
   }
   if (COUNT && lane == 0) {
@@ -741,7 +595,7 @@ int launch_persistent(hipStream_t stream, const RenderParams& P_in, const Persis
   if (cfg.traversal == DR_TRAVERSAL_WIDE) {
     // the cooperative drain shortens a launch's tail; with many tiles per wave the tail does not show and the leaner build is faster
     const bool coop = P.coop_steps > 0 && (long long)work < (long long)cfg.coop_tiles_per_wave * blocks * 4;
-    if (!coop && !DR_WAVE_LOG_DETAIL) log_waves = 0;      // only the work-sharing build writes the log
+    if (!coop) log_waves = 0;      // only the work-sharing build writes the log
     if (cfg.count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, false>), grid, block, 0, stream, P, counter, order, rstart, pixel_cost);
     else if (coop) hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, true>), grid, block, 0, stream, P, counter, order, rstart, pixel_cost);
     else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, false>), grid, block, 0, stream, P, counter, order, rstart, pixel_cost);
@@ -753,40 +607,29 @@ int launch_persistent(hipStream_t stream, const RenderParams& P_in, const Persis
 }
 
 // Six waves per SIMD (occupancy 6): only the wide walk's lean build fits -- 80 VGPRs and 26 KiB of LDS per workgroup -- and only with the
-// default thresholds; every other launch (counting build, work-sharing build of short launches, other tunings) runs five.
+// default schedule; every other launch (counting build, work-sharing build of short launches, other schedules) runs five.
 bool launch_wide_lean6(hipStream_t stream, const RenderParams& P_in, const PersistentCfg& cfg, unsigned* counter, const int* order, const int* rstart, unsigned* pixel_cost, int& log_waves) {
-  if (cfg.traversal != DR_TRAVERSAL_WIDE || cfg.count || cfg.trav_min != 32 || cfg.park_min != 20 || cfg.unroll != 2) return false;
+  if (cfg.traversal != DR_TRAVERSAL_WIDE || cfg.count || cfg.schedule != 0) return false;
   RenderParams P = P_in;
   const long long work = (long long)P.ncols * P.gy * P.batch;
   if (P.coop_steps > 0 && work < (long long)cfg.coop_tiles_per_wave * cfg.num_cus * 5 * 4) return false;      // a short launch: work-sharing build
-#ifndef DR_LEAN_OCC
-#define DR_LEAN_OCC 6      // (experiment builds: 7 or 8 with -DDR_LDS_STACK=10 / 8, timing only)
-#endif
-  int blocks = cfg.num_cus * DR_LEAN_OCC;
+  int blocks = cfg.num_cus * 6;
   if ((long long)blocks * 4 > work) blocks = (int)((work + 3) / 4);
-  if (!DR_WAVE_LOG_DETAIL || blocks * 4 > WAVE_LOG_WAVES) P.wave_log = nullptr;      // only experiment builds log the lean kernel's waves
-  log_waves = P.wave_log ? blocks * 4 : 0;
-#ifndef DR_LEAN_UNROLL
-#define DR_LEAN_UNROLL 2   // (experiment builds: steps per loop iteration of the lean kernel)
-#endif
-  hipLaunchKernelGGL((render_persistent_kernel<false, DR_LEAN_OCC, 32, 20, DR_LEAN_UNROLL, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
+  P.wave_log = nullptr;      // (the lean kernel does not log its waves)
+  log_waves = 0;
+  hipLaunchKernelGGL((render_persistent_kernel<false, 6, 32, 20, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
   return true;
 }
 
-// The instantiated tunings; dr_context_set_option only accepts these values.
+// The instantiated schedules (option "schedule"): 0 = the tuned one -- shade / refill below 32 walking lanes, leaf steps for 20 lanes, two steps per
+// loop iteration --; 1 and 2 keep the other paths of the loop alive in the tests (leaf steps for 8 lanes, one step per iteration; shade / refill
+// below 48 lanes, leaves tested on the spot).  Every other combination rounds 2 and 3 measured is in profiles/r2_*, r3_p_*.
 template <int OCC>
 int launch_persistent_occ(hipStream_t stream, const RenderParams& P, const PersistentCfg& cfg, unsigned* counter, const int* order, const int* rstart, unsigned* pcost) {
-  const int key = cfg.trav_min * 100 + cfg.park_min + 10000 * (cfg.unroll - 1);
-  switch (key) {
-    case 13208: return launch_persistent<OCC, 32, 8, 2>(stream, P, cfg, counter, order, rstart, pcost);
-    case 13216: return launch_persistent<OCC, 32, 16, 2>(stream, P, cfg, counter, order, rstart, pcost);
-    case 13220: return launch_persistent<OCC, 32, 20, 2>(stream, P, cfg, counter, order, rstart, pcost);
-    case 23208: return launch_persistent<OCC, 32, 8, 3>(stream, P, cfg, counter, order, rstart, pcost);
-    case 3200: return launch_persistent<OCC, 32, 0>(stream, P, cfg, counter, order, rstart, pcost);
-    case 4800: return launch_persistent<OCC, 48, 0>(stream, P, cfg, counter, order, rstart, pcost);
-    case 4808: return launch_persistent<OCC, 48, 8>(stream, P, cfg, counter, order, rstart, pcost);
-    case 3216: return launch_persistent<OCC, 32, 16>(stream, P, cfg, counter, order, rstart, pcost);
-    default:   return launch_persistent<OCC, 32, 8>(stream, P, cfg, counter, order, rstart, pcost);
+  switch (cfg.schedule) {
+    case 0:  return launch_persistent<OCC, 32, 20, 2>(stream, P, cfg, counter, order, rstart, pcost);
+    case 1:  return launch_persistent<OCC, 32, 8, 1>(stream, P, cfg, counter, order, rstart, pcost);
+    default: return launch_persistent<OCC, 48, 0, 1>(stream, P, cfg, counter, order, rstart, pcost);
   }
 }
 

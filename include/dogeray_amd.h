@@ -160,7 +160,8 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   ("order_follows_camera", default 1)
  *   "occupancy"     waves per SIMD.  Persistent kernel: 6 (default: six for the wide walk's lean build of long launches, five for
  *                   every other build), 5 or 4; tile kernel: 4 or 6
- *   "trav_min"      32 or 48;  "park_min"  0, 8, 16 or 20 (default);  "unroll"  1, 2 (default) or 3   (persistent kernel scheduling)
+ *   "schedule"      persistent kernel: 0 (default, tuned) = shade / refill once fewer than 32 lanes walk, leaf steps once 20 lanes stand at
+ *                   a leaf, two steps per loop iteration; 1 = 32 / 8 / one step; 2 = 48 / leaves tested on the spot / one step
  *   "xcd_regions"   1 (default): one tile queue per XCD, each an image band, with stealing; 0: one queue
  *   "heavy_factor"  with feedback: tiles that cost more than this many times the mean start first (most expensive
  *                   first), all others keep their natural order (default 1: the above-average tiles; 0: no tile is
@@ -178,12 +179,6 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   Threaded walk ("coop_steps" again): once the queue is empty, a ray older than that is finished by all 64
  *                   lanes breadth-first, in waves with at most "coop_lanes" (8) lanes walking
  *   "wave_log"      1: short launches record begin / queue empty / end of every wave (dr_stats_wave_log)
- *   "paired"        wide walk, launches with many tiles per wave: 1 = every lane owns two paths (one walked, one waiting to be
- *                   shaded or holding the next ray), phase once "pair_thresh" (32, 48, 56) lanes have one to service; measured
- *                   slower than the default one-path kernel, so 0 by default
- *   "roles"         wide walk, launches with many tiles per wave: 3, 7 or 6 = workgroups of 3 / 7 trace waves + one shade wave, or 6 + 2,
- *                   that pass rays and hits through rings in LDS (render_roles_kernel); measured slower than the default
- *                   kernel, so 0 by default
  *   "wide_tree"     tree under the wide walk, read at dr_context_upload_scene: 1 (default) binned surface-area
  *                   heuristic over the leaf boxes, 0 the reference's own topology (K:1745-1861) collapsed 4-way
  * The environment variable DOGERAY_OPTIONS="name=value,..." applies the same at context creation. */
@@ -298,26 +293,16 @@ int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the ke
 int dr_stats_reset(dr_context* c);
 int dr_stats_get(dr_context* c, dr_stats* out);
 
-/* Diagnostics of the pool kernel's counting build (option "pool_diag" = 1), summed over waves since dr_stats_reset, n <= 48 words:
- * [0..2] batches of the node / leaf / shade stage, [3..5] paths in those batches, [6] shader cycles spent choosing a stage and
- * compacting its paths onto the lanes, [7..9] cycles inside the node / leaf / shade step. */
-int dr_stats_kernel_diag(dr_context* c, unsigned long long* out, int n);
-
 /* Timeline of the last SHORT persistent-kernel launch (fewer than coop_tiles_per_wave tiles per wave: one frame, a thin stripe;
  * option "wave_log" = 1 before the launch): sixteen words per wave --
  * begin, first time the wave found the work queue empty (0: never), end, all in 100 MHz ticks of the GPU's
- * real-time counter, and the loop iterations the wave ran after the queue was empty (words 4..15: zero, or detail counts of experiment builds).  Shows where a launch's
+ * real-time counter, and the loop iterations the wave ran after the queue was empty (words 4..15: zero).  Shows where a launch's
  * tail goes (a single frame per launch, K:2154-2224, is mostly tail).  out: 16 * max_waves words. */
 int dr_stats_wave_log(dr_context* c, unsigned long long* out, int max_waves, int* n_waves);
 /* Node steps each pixel of the last frame cost (the persistent kernel's feedback for its tile order, option
  * "feedback"): pixel (tile, lane) at tile * 64 + lane, tile = block column * ceil(H/8) + block row,
  * lane = (x & 7) * 8 + (y & 7).  *n = words written (0: no feedback recorded yet). */
 int dr_stats_pixel_cost(dr_context* c, unsigned* out, size_t capacity, size_t* n);
-/* Experiment builds of the library (-DDR_WAVE_LOG_DETAIL=1, option "wave_log" on): 100 MHz ticks since the launch
- * began at which each pixel of the last single-frame launch was started (first half of out) and finished (second
- * half), indexed like dr_stats_pixel_cost.  *n = 0 in the product build. */
-int dr_stats_pixel_times(dr_context* c, unsigned* out, size_t capacity, size_t* n);
-
 /* Measurement aid (bench.py `roofline.gather`): rate at which this GPU serves divergent, dependent fetches of 64-byte
  * records from the RESIDENT wide-walk array -- the walk's memory behaviour without its arithmetic.  hot_records
  * restricts the random walk to the first records of the array (0 = all of it). */

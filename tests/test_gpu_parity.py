@@ -372,7 +372,6 @@ def test_wave_log_and_pixel_cost_of_a_single_frame(dr, ctx, synth):
         assert np.all(empty > 0)                                  # every wave sees the queue run empty before it ends
         cost = ctx.pixel_cost(W, H)
         assert cost.shape == (W, H) and cost.min() >= 1 and cost.max() < 100000
-        assert ctx.pixel_times(W, H) is None                      # experiment builds only
     finally:
         ctx.set_option("wave_log", 0)
 
@@ -429,21 +428,17 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
     st = dr.pack_settings13(s, 1)
     W, H = 320, 192
     base = None
-    combos = [{"kernel": 0, "occupancy": 4}, {"kernel": 0, "occupancy": 6}, {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 8},
-              {"kernel": 1, "occupancy": 5, "trav_min": 48, "park_min": 0}, {"kernel": 1, "occupancy": 4, "trav_min": 32, "park_min": 16},
-              {"kernel": 1, "occupancy": 4, "trav_min": 48, "park_min": 8, "feedback": 0}, {"kernel": 1, "batch_frames": 3},
-              {"kernel": 1, "trav_min": 32, "park_min": 8, "unroll": 1}, {"kernel": 1, "unroll": 3}, {"kernel": 1, "park_min": 16, "unroll": 2}, {"kernel": 1, "park_min": 20, "occupancy": 5},
+    combos = [{"kernel": 0, "occupancy": 4}, {"kernel": 0, "occupancy": 6}, {"kernel": 1, "occupancy": 4, "schedule": 1},
+              {"kernel": 1, "occupancy": 5, "schedule": 2}, {"kernel": 1, "occupancy": 4, "schedule": 0},
+              {"kernel": 1, "occupancy": 4, "schedule": 2, "feedback": 0}, {"kernel": 1, "batch_frames": 3},
+              {"kernel": 1, "schedule": 1, "occupancy": 5}, {"kernel": 1, "schedule": 0, "occupancy": 5},
               {"kernel": 1, "batch_frames": 1, "coop_steps": 1, "coop_lanes": 64}, {"kernel": 1, "batch_frames": 1, "coop_steps": 0},
               {"kernel": 1, "batch_frames": 2, "coop_steps": 16, "coop_lanes": 4},
               {"kernel": 1, "batch_frames": 1, "split_parts": 4, "split_steps": 32, "coop_rounds": 4, "split_waves": 50}, {"kernel": 1, "batch_frames": 3, "split_parts": 8, "split_steps": 16},
               {"kernel": 1, "batch_frames": 1, "split_parts": 8, "split_steps": 16, "split_waves": 400},
               {"kernel": 1, "batch_frames": 1, "split_parts": 1, "coop_rounds": 1},
               {"kernel": 1, "occupancy": 6, "batch_frames": 32, "coop_tiles_per_wave": 0}, {"kernel": 1, "occupancy": 6, "batch_frames": 1},      # six waves per SIMD (lean wide build)
-              {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 48},       # two paths per lane
-              {"kernel": 1, "batch_frames": 4, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 32},
-              {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 1, "pair_thresh": 56},
-              {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "paired": 0, "roles": 7},                # trace waves + shade wave(s)
-              {"kernel": 1, "batch_frames": 8, "coop_tiles_per_wave": 0, "roles": 6}, {"kernel": 1, "batch_frames": 32, "coop_tiles_per_wave": 0, "roles": 3}]
+              ]
     for opts in combos:
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -454,12 +449,12 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
         if base is None:
             base = acc
         assert np.array_equal(acc, base), opts
-    for k, v in {"kernel": 1, "occupancy": 6, "trav_min": 32, "park_min": 20, "feedback": 1, "batch_frames": 32, "unroll": 2, "coop_steps": 2, "coop_lanes": 8, "coop_rounds": 2,
-                 "split_parts": 4, "split_steps": 400, "split_waves": 12, "coop_tiles_per_wave": 32, "paired": 0, "roles": 0}.items():
+    for k, v in {"kernel": 1, "occupancy": 6, "schedule": 0, "feedback": 1, "batch_frames": 32, "coop_steps": 2, "coop_lanes": 8, "coop_rounds": 2,
+                 "split_parts": 4, "split_steps": 400, "split_waves": 12, "coop_tiles_per_wave": 32}.items():
         ctx.set_option(k, v)
-    assert ctx.get_option("park_min") == 20 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
+    assert ctx.get_option("schedule") == 0 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
     with pytest.raises(dr.DogerayError):
-        ctx.set_option("park_min", 7)
+        ctx.set_option("schedule", 7)
     with pytest.raises(dr.DogerayError):
         ctx.set_option("no_such_option", 1)
     with pytest.raises(dr.DogerayError):
@@ -651,29 +646,6 @@ def test_every_committed_reference_scene_renders_like_the_oracle(dr, orc, ctx, s
             assert stats["node_visits"] == rc["V"] and stats["prim_tests"] == rc["L"]
 
 
-def test_two_paths_per_lane_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
-    """render_paired_kernel (option "paired", off by default): every material, textures, spheres, spp > 1 with a wide lens,
-    margins -- frames identical to the oracle's."""
-    mb4 = with_settings(os.path.join(synth["dir"], "matball.rts"), str(tmp_path / "mb4.rts"),
-                        "*,0,-2.5,7,0.6,0,-0.5,0,7,50,6,4,0.9,synth_env.ppm,192,128")
-    cases = [(mb4, synth["tex"], 192, 128), (os.path.join(SCENES, "scene.rts"), "", 320, 192), (os.path.join(SCENES, "glass.rts"), "", 200, 120),
-             (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192), (os.path.join(synth["dir"], "city_small.rts"), "", 100, 70)]
-    if not ctx.get_option("experimental"):
-        pytest.skip("render_paired_kernel is only in -DDOGERAY_EXPERIMENTAL builds of the library (tools/exp_variant.sh)")
-    ctx.set_option("paired", 1)
-    ctx.set_option("coop_tiles_per_wave", 0)
-    try:
-        for thresh in (32, 48, 56):
-            ctx.set_option("pair_thresh", thresh)
-            for path, tex, W, H in cases:
-                g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, 1, 99, mode=2, kernel=1)
-                _assert_frames(g, r, "%s two paths per lane, threshold %d" % (os.path.basename(path), thresh))
-    finally:
-        ctx.set_option("paired", 0)
-        ctx.set_option("coop_tiles_per_wave", 32)
-        ctx.set_option("pair_thresh", 48)
-
-
 def test_work_sharing_drain_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
     """The drain phase of short launches hands subtrees of the rays still walking to idle lanes (shared best hit by ds_min_u64 on the
     (t, slot) key).  With coop_steps = 1 every ray that can be shared is: fuzzed scenes (coincident triangles: ties must still go
@@ -701,87 +673,6 @@ def test_work_sharing_drain_renders_like_the_oracle(dr, orc, ctx, synth, tmp_pat
         finally:
             for k, v in defaults.items():
                 ctx.set_option(k, v)
-
-
-def test_waves_with_roles_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
-    """render_roles_kernel (option "roles", off by default): trace waves and shade waves exchanging rays and hits through LDS rings --
-    every material, textures, spheres, spp > 1 with a wide lens, margins; frames identical to the oracle's."""
-    mb4 = with_settings(os.path.join(synth["dir"], "matball.rts"), str(tmp_path / "mb4.rts"),
-                        "*,0,-2.5,7,0.6,0,-0.5,0,7,50,6,4,0.9,synth_env.ppm,192,128")
-    cases = [(mb4, synth["tex"], 192, 128), (os.path.join(SCENES, "scene.rts"), "", 320, 192), (os.path.join(SCENES, "glass.rts"), "", 200, 120),
-             (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192), (os.path.join(synth["dir"], "city_small.rts"), "", 100, 70)]
-    if not ctx.get_option("experimental"):
-        pytest.skip("render_roles_kernel is only in -DDOGERAY_EXPERIMENTAL builds of the library (tools/exp_variant.sh)")
-    ctx.set_option("coop_tiles_per_wave", 0)
-    try:
-        for roles in (3, 7, 6):
-            ctx.set_option("roles", roles)
-            for path, tex, W, H in cases:
-                g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, 1, 99, mode=2, kernel=1)
-                _assert_frames(g, r, "%s waves with roles %d" % (os.path.basename(path), roles))
-    finally:
-        ctx.set_option("roles", 0)
-        ctx.set_option("coop_tiles_per_wave", 32)
-
-
-def test_pool_kernel_renders_like_the_oracle(dr, orc, ctx, synth, tmp_path):
-    """render_pool_kernel (kernels_pool.hip, experimental builds; forced for every launch with option "pool" = 2): every wave owns 128
-    paths in LDS and runs one kind of step at a time for up to 64 of them.  Every material, textures, spheres, margins of the preview
-    divisor, frames that are not multiples of 8, fuzzed scenes with coincident triangles (deep trees: stack words in the global scratch),
-    shade thresholds from 1 to 128 -- frames identical to the oracle's."""
-    from scene_fuzz import random_scene
-    rng = np.random.default_rng(2024)
-    names = ["synth_albedo.ppm", "synth_rough.ppm", "synth_env.ppm", "a.ppm"]
-    cube = with_settings(os.path.join(SCENES, "cube.rts"), str(tmp_path / "cube256.rts"), CUBE_SETTINGS)
-    cases = [(cube, "", 256, 256, 1), (cube, "", 256, 256, 4), (os.path.join(SCENES, "scene.rts"), "", 320, 192, 1), (os.path.join(SCENES, "glass.rts"), "", 200, 120, 1),
-             (os.path.join(synth["dir"], "matball.rts"), synth["tex"], 256, 256, 1), (os.path.join(SCENES, "cow.rts"), synth["tex"], 320, 192, 1),
-             (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 320, 192, 1), (os.path.join(synth["dir"], "hf_small.rts"), "", 320, 192, 1),
-             (os.path.join(synth["dir"], "bunny_small.rts"), "", 203, 117, 1), (os.path.join(synth["dir"], "city_small.rts"), "", 640, 360, 1)]
-    cases += [(random_scene(rng, int(rng.integers(2, 900)), str(tmp_path / ("pool%d.rts" % k)), W=96, H=64, textures=names), synth["tex"], 96, 64, 1) for k in range(8)]
-    if not ctx.get_option("experimental"):
-        pytest.skip("render_pool_kernel is only in -DDOGERAY_EXPERIMENTAL builds of the library (tools/exp_variant.sh): measured slower")
-    ctx.set_option("pool", 2)
-    try:
-        for fill, shape in ((48, 0), (1, 1), (128, 2), (48, 1)):      # shape: stack words kept in LDS / waves per CU (4 / 15, 3 / 16, 8 / 12)
-            ctx.set_option("pool_shade_min", fill)
-            ctx.set_option("pool_shape", shape)
-            for path, tex, W, H, div in cases:
-                g, r, stats, rc = _render_pair(dr, orc, ctx, path, tex, W, H, div, 777, spp=1, mode=2, kernel=1)      # (more samples per pixel go to the persistent kernel)
-                _assert_frames(g, r, "%s pool kernel, shade_min %d, shape %d" % (os.path.basename(path), fill, shape))
-    finally:
-        ctx.set_option("pool", 0)
-        ctx.set_option("pool_shade_min", 48)
-        ctx.set_option("pool_shape", 0)
-
-
-def test_pool_kernel_batched_accumulation(dr, orc, ctx, synth):
-    """Several frames per launch of the pool kernel (one tile queue over all of them, atomic adds): the accumulator equals the sum
-    of the oracle's frames; with the tile order of the cost feedback, with and without one queue per XCD."""
-    path = os.path.join(synth["dir"], "city_small.rts")
-    ps, os_ = _load_both(dr, orc, path)
-    ctx.upload(ps)
-    s = ps.settings()
-    st = dr.pack_settings13(s, 1)
-    W, H, n = 640, 360, 7
-    total = np.zeros((W, H, 3), dtype=np.int64)
-    for k in range(n):
-        f, _ = os_.render(st, W, H, s.background, 5 + 1000003 * k, nthreads=4)
-        total += f
-    if not ctx.get_option("experimental"):
-        pytest.skip("render_pool_kernel is only in -DDOGERAY_EXPERIMENTAL builds of the library")
-    ctx.set_option("pool", 2)
-    try:
-        for regions in (1, 0):
-            ctx.set_option("xcd_regions", regions)
-            ctx.set_option("short_one_queue", 0)
-            for rep in range(3):          # the second and third launch run with the order the first one's costs gave
-                ctx.accum_reset(W, H)
-                ctx.render_accumulate(st, W, H, s.background, 5, 1000003, n)
-                assert np.array_equal(ctx.accum_read().astype(np.int64), total), (regions, rep)
-    finally:
-        ctx.set_option("pool", 0)
-        ctx.set_option("xcd_regions", 1)
-        ctx.set_option("short_one_queue", 1)
 
 
 def test_fuzz_campaign_slice(dr, orc, ctx, synth, tmp_path):

@@ -59,10 +59,10 @@ static void wide_hit(const std::vector<DevUnit>& rec, float pmax, const float o[
     } else {
       ws.nodes++;
       const unsigned base = w[3] & 0xffffffu, valid = w[7] & 15u, leafmask = (w[7] >> 4) & 15u;
-      // the kernel's folded test (wide_node_test, DR_WIDE_FOLD) and, as a check, the plain decode-and-slab test it must cover
+      // the kernel's folded test (wide_node_test) and, as a check, the plain decode-and-slab test it must cover
       unsigned mask_plain = 0, key = 0xffffffffu; float dist[4] = {0, 0, 0, 0};
       u32x4 RA, RB, RC, RD; memcpy(&RA, w, 16); memcpy(&RB, w + 4, 16); memcpy(&RC, w + 8, 16); memcpy(&RD, w + 12, 16);
-      unsigned mask = wide_node_test(RA, RB, RC, RD, mk(o[0], o[1], o[2]), mk(inv[0], inv[1], inv[2]), wr, best_t, key);      // the kernel's test
+      unsigned mask = wide_node_test(RA, RB, RC, RD, mk(inv[0], inv[1], inv[2]), wr, best_t, key);      // the kernel's test
       float nearest_plain = INFINITY;
       for (int k = 0; k < 4; k++) {
         float mn[3], mx[3];
