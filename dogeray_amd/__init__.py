@@ -422,7 +422,7 @@ class Context:
         _check(lib().dr_stats_get(self._h, C.byref(s)))
         return s.as_dict()
 
-    def wave_log(self, max_waves=49152):
+    def wave_log(self, max_waves=16384):
         """(n, 16) uint64: begin, queue-empty, end stamps (100 MHz ticks) and iterations after the queue was empty, per wave of the
         last persistent launch; needs set_option("wave_log", 1) before the launch."""
         out = np.zeros((max_waves, 16), dtype=np.uint64)

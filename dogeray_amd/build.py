@@ -8,7 +8,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdogeray_amd.so")
 HOST_SOURCES = ["rts_reader.cpp", "bvh_builder.cpp", "linearise.cpp", "wide_builder.cpp", "capi_host.cpp", "group.cpp", "context.cpp"]
 # one translation unit per family of kernels (kernels.hpp)
-DEVICE_SOURCES = ["kernels_render.hip", "kernels_handoff.hip", "kernels_aux.hip"]
+DEVICE_SOURCES = ["kernels_render.hip", "kernels_aux.hip"]
 # -ffp-contract=off: no FMA contraction on host or device -- the BVH build and the kernel's
 # arithmetic are specified operation by operation (DESIGN.md "arithmetic contract").
 COMMON = ["-std=c++17", "-O3", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wextra",

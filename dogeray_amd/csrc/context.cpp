@@ -69,16 +69,6 @@ struct dr_context {
   int split_steps = 400;    // ... tiles whose longest pixel took at least this many node steps (multiple of 16)
   int short_one_queue = 1;  // short launches use one tile queue instead of one per XCD
   int coop_rounds = 2;      // work sharing: hand-over rounds per loop iteration
-  // short launches of the wide walk as a chain of kernels (kernels_handoff.hip): lean build on the tile queues -> its live paths in a list -> work-sharing build
-  int handoff = 1;          // 0: one kernel (the work-sharing build from the start), as before round 4
-  int handoff_wait = 8;     // loop iterations a wave of the first stage goes on after it knows the queues are empty, before it hands its paths on
-  int duo_exp = 0;          // EXPERIMENT (frames incomplete): 1 = short launches render every tile but the split ones, lean chain on five workgroups per CU; 2 = only the split ones, work-sharing build on one workgroup per CU
-  int handoff_mid = 0;      // a middle stage between the two: 1 = lean build, 2 = work-sharing build without sharing; runs handoff_mid_wait iterations, dumps what is left
-  int handoff_mid_wait = 24;
-  uint32_t* handoff_list[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};      // per render stream (the pipeline has up to four)
-  int handoff_cap = 0;      // entries each list has room for
-  uint32_t* handoff_flags[4] = {nullptr, nullptr, nullptr, nullptr}; uint32_t handoff_epoch[4] = {0, 0, 0, 0};      // per render stream: the chains' "queues empty" flag and their count
-  int stream_index = 0;     // which render stream enqueue_frame is queueing on (dr_pipeline_submit sets it)
   int wave_log_on = 0;      // persistent kernel writes begin / queue-empty / end stamps of every wave (dr_stats_wave_log)
   unsigned long long* wave_log = nullptr; int wave_log_waves = 0;
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
@@ -163,8 +153,7 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   return DR_OK;
 }
 
-constexpr int TILE_COUNTERS = 4096;                              // 32-bit words of the launch-control buffer
-constexpr int LAUNCH_CTL_WORDS = MAX_REGIONS + HANDOFF_CTL_WORDS;      // per launch: one tile counter per region, then the hand-off chain's control words
+constexpr int TILE_COUNTERS = 1024;
 
 // the traversal a launch really uses: the wide walk needs its structure (scenes it cannot represent walk the threaded links)
 inline int traversal_of(const dr_context* c) { return (c->traversal == DR_TRAVERSAL_WIDE && !c->wide) ? DR_TRAVERSAL_THREADED : c->traversal; }
@@ -208,40 +197,17 @@ PersistentCfg persistent_cfg(const dr_context* c) {
   return cfg;
 }
 
-// A short launch of the wide walk runs as a chain of kernels (kernels_handoff.hip) when the option is on, the tuned schedule and six waves per SIMD are
-// selected (the chain's builds exist for those) and the lists are to be had: 2 x 71 MB per render stream on a 256-CU part, allocated on first use.
-bool handoff_plan(dr_context* c, const RenderParams& P, const PersistentCfg& cfg, unsigned* ctl, HandoffPlan& plan) {
-  if (!c->handoff || cfg.schedule != 0 || cfg.occupancy < 6 || !persistent_launch_is_short(P, cfg)) return false;
-  const int cap = c->num_cus * 6 * 4 * 128;                  // every lane of every wave the lean stage can have, and as many pixels of its last tile not yet started
-  const int si = c->stream_index;
-  if (c->handoff_cap != cap) {
-    for (auto& pair : c->handoff_list) for (uint32_t*& l : pair) if (l) { (void)hipFree(l); l = nullptr; }
-    c->handoff_cap = cap;
-  }
-  for (uint32_t*& l : c->handoff_list[si])
-    if (!l && hipMalloc((void**)&l, (size_t)cap * HANDOFF_WORDS * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); l = nullptr; return false; }
-  if (!c->handoff_flags[si]) {
-    if (hipMalloc((void**)&c->handoff_flags[si], HANDOFF_FLAG_WORDS * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); c->handoff_flags[si] = nullptr; return false; }
-    (void)hipMemsetAsync(c->handoff_flags[si], 0, HANDOFF_FLAG_WORDS * sizeof(uint32_t), c->stream);
-    c->handoff_epoch[si] = 0;
-  }
-  plan.flags = c->handoff_flags[si]; plan.epoch = ++c->handoff_epoch[si];
-  plan.ctl = ctl; plan.list[0] = c->handoff_list[si][0]; plan.list[1] = c->handoff_list[si][1]; plan.cap = cap;
-  plan.wait = c->handoff_wait; plan.mid = c->handoff_mid; plan.mid_wait = c->handoff_mid_wait;
-  return true;
-}
-
 // enqueue one launch (P.batch frames); no events, no sync
 void enqueue_frame(dr_context* c, const RenderParams& P_in) {
   RenderParams P = P_in;
   const int tiles = P.ncols * P.gy;
   if (uses_persistent(c)) {
-    if (c->tile_cursor + LAUNCH_CTL_WORDS > TILE_COUNTERS) {
+    if (c->tile_cursor + MAX_REGIONS > TILE_COUNTERS) {
       (void)hipMemsetAsync(c->tile_counters, 0, TILE_COUNTERS * sizeof(unsigned), c->stream);
       c->tile_cursor = 0;
     }
-    unsigned* counter = c->tile_counters + c->tile_cursor;      // one counter per region, then the control words of a hand-off chain (all zero)
-    c->tile_cursor += LAUNCH_CTL_WORDS;
+    unsigned* counter = c->tile_counters + c->tile_cursor;      // one counter per region
+    c->tile_cursor += MAX_REGIONS;
     const int* order; unsigned* pcost;
     if (c->pipe_hold_order) {
       // a pipelined launch runs beside the previous frame's: it may read the tile order but nobody may write it (or the costs) meanwhile
@@ -250,12 +216,7 @@ void enqueue_frame(dr_context* c, const RenderParams& P_in) {
       pcost = nullptr;
     } else feedback_buffers(c, P, tiles, order, pcost);
     if (!c->wave_log_on) P.wave_log = nullptr;
-    PersistentCfg cfg = persistent_cfg(c);
-    if (c->duo_exp && order && P.batch == 1 && persistent_launch_is_short(P, cfg)) { P.duo = c->duo_exp; cfg.wgs_per_cu = c->duo_exp == 1 ? 5 : 1; }
-    HandoffPlan plan;
-    if (P.wave_log) (void)hipMemsetAsync(c->wave_log, 0, (size_t)WAVE_LOG_WAVES * 16 * sizeof(unsigned long long), c->stream);      // (waves of a chain that end at once write nothing)
-    if (P.duo != 2 && handoff_plan(c, P, cfg, counter + MAX_REGIONS, plan)) c->wave_log_waves = launch_handoff_chain(c->stream, P, cfg, counter, order, c->region_start, pcost, plan);
-    else c->wave_log_waves = launch_persistent_kernel(c->stream, P, cfg, counter, order, c->region_start, pcost);
+    c->wave_log_waves = launch_persistent_kernel(c->stream, P, persistent_cfg(c), counter, order, c->region_start, pcost);
     // next launch's order from this launch's costs (stream-ordered, no host sync).  The view does not change between the frames of
     // a progressive render, so after the first two launches of a view the order is refreshed every feedback_every-th launch only
     // (the two kernels take 75 us: nothing for a launch of 32 frames, 6 % of a launch of one)
@@ -285,11 +246,6 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "split_steps") { if (v < 16 || v > 4080) goto bad; c->split_steps = v & ~15; c->order_valid = false; }
   else if (name == "short_one_queue") { c->short_one_queue = v != 0; c->order_valid = false; }
   else if (name == "coop_rounds") { if (v < 1 || v > 16) goto bad; c->coop_rounds = v; }
-  else if (name == "handoff") { c->handoff = v != 0; }
-  else if (name == "handoff_wait") { if (v < 0 || v > 100000) goto bad; c->handoff_wait = v; }
-  else if (name == "duo_exp") { if (v < 0 || v > 2) goto bad; c->duo_exp = v; }
-  else if (name == "handoff_mid") { if (v < 0 || v > 2) goto bad; c->handoff_mid = v; }
-  else if (name == "handoff_mid_wait") { if (v < 0 || v > 100000) goto bad; c->handoff_mid_wait = v; }
   else if (name == "wave_log") {
     if (v != 0 && v != 1) goto bad;
     if (v && !c->wave_log) {
@@ -446,8 +402,6 @@ void dr_context_destroy(dr_context* c) {
   if (c->acc_stream) (void)hipStreamSynchronize(c->acc_stream);
   void* bufs[] = {c->wave_log, c->packed[0], c->packed[1], c->walk, c->wide, c->pairs, c->prims, c->shade, c->tex, c->texels, c->frame, c->accum, c->present, c->counters, c->tile_counters, c->pixel_cost, c->tile_cost, c->tile_order, c->region_start};
   for (void* b : bufs) if (b) (void)hipFree(b);
-  for (auto& pair : c->handoff_list) for (uint32_t* l : pair) if (l) (void)hipFree(l);
-  for (uint32_t* f : c->handoff_flags) if (f) (void)hipFree(f);
   if (c->ev0) (void)hipEventDestroy(c->ev0);
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int k = 0; k < 2; k++) { if (c->pev0[k]) (void)hipEventDestroy(c->pev0[k]); if (c->pev1[k]) (void)hipEventDestroy(c->pev1[k]); }
@@ -526,11 +480,6 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_lanes") *value = c->coop_lanes;
   else if (n == "wave_log") *value = c->wave_log_on;
   else if (n == "coop_rounds") *value = c->coop_rounds;
-  else if (n == "handoff") *value = c->handoff;
-  else if (n == "handoff_wait") *value = c->handoff_wait;
-  else if (n == "duo_exp") *value = c->duo_exp;
-  else if (n == "handoff_mid") *value = c->handoff_mid;
-  else if (n == "handoff_mid_wait") *value = c->handoff_mid_wait;
   else if (n == "short_one_queue") *value = c->short_one_queue;
   else if (n == "split_parts") *value = c->split_parts;
   else if (n == "split_steps") *value = c->split_steps;
@@ -744,15 +693,15 @@ int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, 
   if (c->pipe_barrier_set) HIP_TRY(hipStreamWaitEvent(rs, c->pipe_barrier, 0));
   // the tile counters are cleared (on this launch's stream) when the cursor wraps: like a refresh, that launch runs alone -- nobody may
   // still count on the old values, and nobody may start on the new ones before they are cleared
-  const bool alone = refresh || c->tile_cursor + LAUNCH_CTL_WORDS > TILE_COUNTERS;
+  const bool alone = refresh || c->tile_cursor + MAX_REGIONS > TILE_COUNTERS;
   if (alone)
     for (int q = 0; q < dr_context::PIPE_STREAMS; q++) if (q != si && c->pipe_last_set[q]) HIP_TRY(hipStreamWaitEvent(rs, c->pipe_last[q], 0));
   if (tiles > 0) {
     hipStream_t saved = c->stream;
-    c->stream = rs; c->stream_index = si; c->pipe_hold_order = !refresh;
+    c->stream = rs; c->pipe_hold_order = !refresh;
     if (c->pipe_lean) c->coop_tiles_per_wave = 0;
     enqueue_frame(c, P);
-    c->stream = saved; c->stream_index = 0; c->pipe_hold_order = false; c->coop_tiles_per_wave = saved_ctpw;
+    c->stream = saved; c->pipe_hold_order = false; c->coop_tiles_per_wave = saved_ctpw;
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipEventRecord(c->pipe_last[si], rs)); c->pipe_last_set[si] = true;

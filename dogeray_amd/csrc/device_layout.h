@@ -134,7 +134,6 @@ struct RenderParams {
   int32_t coop_lanes;             // ... in waves with at most this many lanes still walking
   int32_t split_parts;            // work-sharing build: parts in which the tiles at the head of the order are handed out (1 = whole)
   int32_t coop_rounds;            // work sharing: hand-over rounds per loop iteration
-  int32_t duo;                    // short launches as two kernels side by side: 1 = this one renders every tile but the head of the order (the tiles that are split), 2 = only those; 0 = all
   int32_t regions;                // persistent kernel: number of tile queues (1, or 8 = one per XCD)
   int32_t region_start[9];        // identity order: region r owns tiles [region_start[r], region_start[r+1])
 };

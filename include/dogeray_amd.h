@@ -178,12 +178,6 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   help with their rays from the first step
  *                   Threaded walk ("coop_steps" again): once the queue is empty, a ray older than that is finished by all 64
  *                   lanes breadth-first, in waves with at most "coop_lanes" (8) lanes walking
- *   "handoff"       1 (default): a short launch of the wide walk is a CHAIN of kernels on one stream -- the lean six-wave build renders from the
- *                   tile queues; a wave that finds them empty writes its live paths to a list and ends; the work-sharing build starts from that
- *                   list, the paths spread evenly over its waves, every other lane a helper from the first step on (so the bulk runs at the lean
- *                   build's rate and only the tail pays for work sharing; no tile is split then).  "handoff_mid" 1 / 2 puts a stage between the two
- *                   that runs "handoff_mid_wait" loop iterations without sharing (lean / work-sharing build) and dumps what is left.
- *                   0: one kernel, the work-sharing build from the start (rounds 2-3)
  *   "wave_log"      1: short launches record begin / queue empty / end of every wave (dr_stats_wave_log)
  *   "wide_tree"     tree under the wide walk, read at dr_context_upload_scene: 1 (default) binned surface-area
  *                   heuristic over the leaf boxes, 0 the reference's own topology (K:1745-1861) collapsed 4-way
@@ -303,8 +297,7 @@ int dr_stats_get(dr_context* c, dr_stats* out);
  * option "wave_log" = 1 before the launch): sixteen words per wave --
  * begin, first time the wave found the work queue empty (0: never), end, all in 100 MHz ticks of the GPU's
  * real-time counter, and the loop iterations the wave ran after the queue was empty (words 4..15: zero).  Shows where a launch's
- * tail goes (a single frame per launch, K:2154-2224, is mostly tail).  A chain of kernels ("handoff") logs stage s at wave
- * s * 16384 + w; waves that ended at once (no path for them) stay zero.  out: 16 * max_waves words. */
+ * tail goes (a single frame per launch, K:2154-2224, is mostly tail).  out: 16 * max_waves words. */
 int dr_stats_wave_log(dr_context* c, unsigned long long* out, int max_waves, int* n_waves);
 /* Node steps each pixel of the last frame cost (the persistent kernel's feedback for its tile order, option
  * "feedback"): pixel (tile, lane) at tile * 64 + lane, tile = block column * ceil(H/8) + block row,

@@ -363,22 +363,17 @@ def test_wave_log_and_pixel_cost_of_a_single_frame(dr, ctx, synth):
     plain = ctx.render_frame(st, W, H, s.background, 5)
     ctx.set_option("wave_log", 1)
     try:
-        for handoff in (1, 0):      # the chain of kernels (stage s logs at wave s * 16384 + w; waves without a path stay zero), and the single work-sharing kernel
-            ctx.set_option("handoff", handoff)
-            again = ctx.render_frame(st, W, H, s.background, 5)
-            assert np.array_equal(plain, again)
-            log = ctx.wave_log()
-            assert len(log) > 0 and len(log) % 4 == 0
-            log = log[log[:, 0] > 0]
-            assert len(log) > 0
-            begin, empty, end = log[:, 0].astype(np.int64), log[:, 1].astype(np.int64), log[:, 2].astype(np.int64)
-            assert np.all(end >= begin) and np.all((empty == 0) | ((empty >= begin) & (empty <= end)))
-            assert np.all(empty > 0)                                  # every wave sees the queue run empty before it ends
-            cost = ctx.pixel_cost(W, H)
-            assert cost.shape == (W, H) and cost.min() >= 1 and cost.max() < 100000
+        again = ctx.render_frame(st, W, H, s.background, 5)
+        assert np.array_equal(plain, again)
+        log = ctx.wave_log()
+        assert len(log) > 0 and len(log) % 4 == 0
+        begin, empty, end = log[:, 0].astype(np.int64), log[:, 1].astype(np.int64), log[:, 2].astype(np.int64)
+        assert np.all(end >= begin) and np.all((empty == 0) | ((empty >= begin) & (empty <= end)))
+        assert np.all(empty > 0)                                  # every wave sees the queue run empty before it ends
+        cost = ctx.pixel_cost(W, H)
+        assert cost.shape == (W, H) and cost.min() >= 1 and cost.max() < 100000
     finally:
         ctx.set_option("wave_log", 0)
-        ctx.set_option("handoff", 1)
 
 
 def test_stripes_partition_the_frame(dr, ctx, synth):
@@ -443,10 +438,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
               {"kernel": 1, "batch_frames": 1, "split_parts": 8, "split_steps": 16, "split_waves": 400},
               {"kernel": 1, "batch_frames": 1, "split_parts": 1, "coop_rounds": 1},
               {"kernel": 1, "occupancy": 6, "batch_frames": 32, "coop_tiles_per_wave": 0}, {"kernel": 1, "occupancy": 6, "batch_frames": 1},      # six waves per SIMD (lean wide build)
-              # short launches as a chain of kernels (lean build -> list of live paths -> work-sharing build), with and without a middle stage
-              {"kernel": 1, "batch_frames": 1, "handoff": 0}, {"kernel": 1, "batch_frames": 1, "handoff": 1, "handoff_wait": 0, "handoff_mid": 1, "handoff_mid_wait": 3},
-              {"kernel": 1, "batch_frames": 3, "handoff": 1, "handoff_mid": 2, "handoff_mid_wait": 0}, {"kernel": 1, "batch_frames": 1, "handoff": 1, "handoff_mid": 1, "handoff_mid_wait": 40},
-              {"kernel": 1, "batch_frames": 2, "handoff": 1, "handoff_wait": 2, "handoff_mid": 0, "coop_steps": 1, "coop_rounds": 4}]
+              ]
     for opts in combos:
         for k, v in opts.items():
             ctx.set_option(k, v)
@@ -458,7 +450,7 @@ def test_tuning_options_do_not_change_pixels(dr, ctx, synth):
             base = acc
         assert np.array_equal(acc, base), opts
     for k, v in {"kernel": 1, "occupancy": 6, "schedule": 0, "feedback": 1, "batch_frames": 32, "coop_steps": 2, "coop_lanes": 8, "coop_rounds": 2,
-                 "split_parts": 4, "split_steps": 400, "split_waves": 12, "coop_tiles_per_wave": 32, "handoff": 1, "handoff_wait": 8, "handoff_mid": 0, "handoff_mid_wait": 24}.items():
+                 "split_parts": 4, "split_steps": 400, "split_waves": 12, "coop_tiles_per_wave": 32}.items():
         ctx.set_option(k, v)
     assert ctx.get_option("schedule") == 0 and ctx.get_option("batch_frames") == 32 and ctx.get_option("tree_depth") == 11   # 1 730 leaves
     with pytest.raises(dr.DogerayError):
@@ -664,15 +656,13 @@ def test_work_sharing_drain_renders_like_the_oracle(dr, orc, ctx, synth, tmp_pat
     cases = [(random_scene(rng, int(rng.integers(50, 900)), str(tmp_path / ("share%d.rts" % k)), W=96, H=64, textures=names), synth["tex"], 96, 64) for k in range(6)]
     cases += [(os.path.join(SCENES, "scene.rts"), "", 320, 192), (os.path.join(synth["dir"], "hf_small.rts"), "", 320, 192),
               (os.path.join(synth["dir"], "city_small.rts"), "", 200, 120)]
-    defaults = {k: ctx.get_option(k) for k in ("coop_steps", "coop_lanes", "coop_rounds", "split_parts", "split_steps", "split_waves", "handoff", "handoff_wait", "handoff_mid", "handoff_mid_wait")}
+    defaults = {k: ctx.get_option(k) for k in ("coop_steps", "coop_lanes", "coop_rounds", "split_parts", "split_steps", "split_waves")}
     # split_parts / split_steps: tiles whose longest pixel took split_steps node steps in the previous frame are handed out in parts and
     # the rest of each wave helps from the start; _render_pair renders every frame twice (the second launch has the first one's costs),
     # so the split path runs
     combos = ({"coop_steps": 1, "coop_lanes": 64, "split_parts": 1}, {"coop_steps": 4, "coop_rounds": 1, "split_parts": 1}, {"coop_steps": 8, "coop_rounds": 4},
               {"coop_steps": 1, "split_parts": 4, "split_steps": 16, "coop_rounds": 3}, {"coop_steps": 2, "split_parts": 2, "split_steps": 32},
-              {"split_parts": 8, "split_steps": 16, "split_waves": 50}, {"split_parts": 8, "split_steps": 64, "coop_steps": 1, "coop_rounds": 16, "split_waves": 1000},
-              {"handoff": 0, "coop_steps": 1, "split_parts": 4, "split_steps": 16}, {"handoff": 1, "handoff_wait": 0, "handoff_mid": 1, "handoff_mid_wait": 2, "coop_steps": 1},
-              {"handoff": 1, "handoff_mid": 2, "handoff_mid_wait": 5, "coop_steps": 2, "coop_rounds": 8})
+              {"split_parts": 8, "split_steps": 16, "split_waves": 50}, {"split_parts": 8, "split_steps": 64, "coop_steps": 1, "coop_rounds": 16, "split_waves": 1000})
     for combo in combos:
         for k, v in combo.items():
             ctx.set_option(k, v)

@@ -8,7 +8,7 @@ NAME=$1; FLAGS=$2
 R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/tools/_exp /tmp/exp_$NAME
 OBJS=""
-for f in kernels_render kernels_handoff kernels_aux; do
+for f in kernels_render kernels_aux; do
   /opt/rocm/bin/hipcc -std=c++17 -O3 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize ${SCHED--mllvm -enable-post-misched=0 -mllvm -amdgpu-use-amdgpu-trackers=1} $FLAGS --offload-arch=gfx950 -c $R/dogeray_amd/csrc/$f.hip -o /tmp/exp_$NAME/$f.o &
   OBJS="$OBJS /tmp/exp_$NAME/$f.o"
 done
