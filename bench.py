@@ -165,6 +165,13 @@ def algorithmic_bytes(c, frames, W, H):
     return 32 * c["node_visits"] + 36 * c["prim_tests"] + 128 * c["shades"] + 4 * c["texels"] + 12 * W * H * frames
 
 
+def metric_label(args, W, H):
+    """BASELINE.json's metric, named for the configuration that is run (--config)."""
+    if args.config == "C4":
+        return "Mrays/sec + ms/frame, 1M-tri .rts at 1920x1080"
+    return "Mrays/sec + ms/frame, config %s at %dx%d (BASELINE.json's headline is C4: 1M-tri .rts at 1920x1080)" % (args.config, W, H)
+
+
 def main_group(args):
     """`python bench.py --gpus N` without a launcher: the N ranks are the library's dr_group -- one context and one host thread
     per GPU in THIS process, stripes gathered to rank 0 by ncclSend / grouped ncclRecv on a second stream per rank (peer copies
@@ -190,6 +197,8 @@ def main_group(args):
     for c in ctxs:
         c.set_traversal(mode)
         c.set_option("batch_frames", min(args.batch, 256))
+        if os.environ.get("DOGERAY_RESERVE_CUS"):      # experiment: room for the gather beside the rendering
+            c.set_option("reserve_cus", int(os.environ["DOGERAY_RESERVE_CUS"]))
     st = dr.pack_settings13(s, 1, spp=1)
     log("scene %s: %d triangles, parse %.1fs, BVH %.1fs, upload on %d ranks %.2fs; transport %s" % (
         os.path.basename(scene_path), ntris, t_parse, t_bvh, N, t_upload, "rccl" if grp.uses_rccl else "copy"))
@@ -200,7 +209,7 @@ def main_group(args):
         grp.render_accumulate(st, W, H, s.background, seed_base + first * seed_stride, seed_stride, count, args.gather_every)
 
     run_frames(0, args.warmup)
-    region_s, timed = [], None
+    region_s, reps = [], []
     for rep in range(max(1, args.repeats)):
         for c in ctxs:
             c.stats_reset()
@@ -208,12 +217,10 @@ def main_group(args):
         run_frames(args.warmup, args.steps)
         dt = time.perf_counter() - t0
         region_s.append(dt)
-        st_rep = [c.stats() for c in ctxs]
-        slowest = max(x["kernel_ms"] for x in st_rep)
-        if timed is None or slowest < timed[0]:
-            timed = (slowest, st_rep)
+        reps.append((dt, [c.stats() for c in ctxs]))
     srt = sorted(region_s)
     elapsed = srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2])
+    timed = min(reps, key=lambda r: abs(r[0] - elapsed))      # the statistics of the MEDIAN repeat, the one `value` is quoted on (as the one-GPU path does)
     # the assembled accumulator against one context rendering the whole frame: the same frames, bit for bit
     grp.accum_reset(W, H)
     run_frames(args.warmup, min(args.steps, 4))
@@ -239,7 +246,7 @@ def main_group(args):
     frames = args.steps
     per_rank_ms = [x["kernel_ms"] for x in timed[1]]
     result = {
-        "metric": "Mrays/sec + ms/frame, 1M-tri .rts at 1920x1080",
+        "metric": metric_label(args, W, H),
         "value": rays / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / frames * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -257,6 +264,9 @@ def main_group(args):
         "repeats": len(region_s), "ms_per_step_min": min(region_s) / frames * 1e3, "ms_per_step_max": max(region_s) / frames * 1e3,
         "rays_per_frame": rays / frames, "primary_samples_per_s": (W * H * frames) / elapsed,
         "kernel_ms_per_rank": per_rank_ms,
+        # what the timed region spends outside the slowest rank's kernels (host threads, gather of the last batch): region wall - max rank kernel time
+        "region_ms": timed[0] * 1e3, "region_minus_slowest_rank_ms": timed[0] * 1e3 - max(per_rank_ms),
+        "region_overhead_frac": (timed[0] * 1e3 - max(per_rank_ms)) / (timed[0] * 1e3),
         "setup_s": {"parse": t_parse, "bvh_build": t_bvh, "upload": t_upload},
         "roofline": None, "cpu_baseline": None,
         "note": "roofline and cpu_baseline are reported by the one-GPU run (same kernels; N = 1 is the configuration the metric is quoted on)",

@@ -69,6 +69,7 @@ struct dr_context {
   int split_steps = 400;    // ... tiles whose longest pixel took at least this many node steps (multiple of 16)
   int short_one_queue = 1;  // short launches use one tile queue instead of one per XCD
   int coop_rounds = 2;      // work sharing: hand-over rounds per loop iteration
+  int reserve_cus = 0;      // persistent kernel: launch workgroups for this many CUs fewer than the device has (room for a gather's copy / RCCL kernels beside the rendering)
   int wave_log_on = 0;      // persistent kernel writes begin / queue-empty / end stamps of every wave (dr_stats_wave_log)
   unsigned long long* wave_log = nullptr; int wave_log_waves = 0;
   int batch_frames = 32;    // persistent kernel: at most this many frames per launch in dr_render_accumulate
@@ -193,7 +194,7 @@ void feedback_buffers(dr_context* c, const RenderParams& P, int tiles, const int
 PersistentCfg persistent_cfg(const dr_context* c) {
   PersistentCfg cfg;
   cfg.traversal = traversal_of(c); cfg.occupancy = c->occupancy; cfg.schedule = c->schedule;
-  cfg.num_cus = c->num_cus; cfg.coop_tiles_per_wave = c->coop_tiles_per_wave; cfg.count = c->count;
+  cfg.num_cus = c->num_cus - c->reserve_cus > 0 ? c->num_cus - c->reserve_cus : 1; cfg.coop_tiles_per_wave = c->coop_tiles_per_wave; cfg.count = c->count;
   return cfg;
 }
 
@@ -246,6 +247,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "split_steps") { if (v < 16 || v > 4080) goto bad; c->split_steps = v & ~15; c->order_valid = false; }
   else if (name == "short_one_queue") { c->short_one_queue = v != 0; c->order_valid = false; }
   else if (name == "coop_rounds") { if (v < 1 || v > 16) goto bad; c->coop_rounds = v; }
+  else if (name == "reserve_cus") { if (v < 0 || v > 64) goto bad; c->reserve_cus = v; }
   else if (name == "wave_log") {
     if (v != 0 && v != 1) goto bad;
     if (v && !c->wave_log) {
@@ -480,6 +482,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_lanes") *value = c->coop_lanes;
   else if (n == "wave_log") *value = c->wave_log_on;
   else if (n == "coop_rounds") *value = c->coop_rounds;
+  else if (n == "reserve_cus") *value = c->reserve_cus;
   else if (n == "short_one_queue") *value = c->short_one_queue;
   else if (n == "split_parts") *value = c->split_parts;
   else if (n == "split_steps") *value = c->split_steps;

@@ -13,12 +13,19 @@
 // sent(k-2)).  Transport: RCCL point-to-point (ncclSend / ncclRecv, grouped on rank 0: the R-1 transfers land on R-1
 // distinct xGMI links), resolved from librccl.so at run time; DOGERAY_GROUP_TRANSPORT=copy (or several ranks on one
 // device, as the single-GPU tests do) uses hipMemcpyPeerAsync + events instead.
+// Threads: one per rank, created with the group and fed jobs through a condition variable (none is created inside a render call).
+// Failure: a rank that fails records the first error, releases the rendezvous and raises `failed`; every other rank sees the flag before its next
+// RCCL call or while it waits for its streams -- that wait is a hipStreamQuery poll with a deadline (DOGERAY_GROUP_TIMEOUT_S, default 30 s), never a
+// bare hipStreamSynchronize -- and returns.  Only then, when no rank thread is inside RCCL any more, the coordinator aborts the communicators
+// (transfers that will never be matched are cancelled) and marks the group broken.  A failed upload breaks nothing.
 // This file is a client of the C ABI (include/dogeray_amd.h) plus HIP events/streams and RCCL: no kernels.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
 #include <dlfcn.h>
 
+#include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <cstdlib>
 #include <cstring>
@@ -95,19 +102,19 @@ struct dr_group {
   Rendezvous meet;
   std::string error;                               // first failure of a worker
   std::mutex error_lock;
-  bool broken = false;                             // a rank failed under RCCL: the communicators were aborted, the group can only be destroyed
-  // A rank that fails leaves its peers with transfers that will never be matched: rank 0 has already queued grouped ncclRecv
-  // calls for it, and hipStreamSynchronize(comm) / the join would wait for ever.  So the first failure aborts every
-  // communicator (ncclCommAbort cancels outstanding send / recv; the waiting threads then return) and releases the copy
-  // transport's rendezvous.  The group is unusable afterwards and says so.
+  std::atomic<bool> failed{false};                 // a rank failed in the call that is running: the others stop at their next check
+  bool broken = false;                             // a render call failed under RCCL: the communicators were aborted, the group can only be destroyed
+  double timeout_s = 30.0;                         // deadline of a rank's wait for its streams (DOGERAY_GROUP_TIMEOUT_S)
+  int fail_rank = -1, fail_batch = -1;             // failure injection for the tests (DOGERAY_GROUP_FAIL_RANK / _BATCH): that rank fails before queuing that batch
+  // rank threads: created with the group, one job at a time for all of them
+  std::vector<std::thread> threads;
+  std::mutex job_lock; std::condition_variable job_cv, done_cv;
+  std::function<bool(int)> job; unsigned long job_id = 0; int job_left = 0; bool quit = false;
+  std::vector<char> job_ok;
+  // the first error of a call; wakes everybody who waits for the failed rank.  Touches no communicator: the rank threads may be inside RCCL.
   void fail(const std::string& msg) {
-    bool first = false;
-    { std::lock_guard<std::mutex> g(error_lock); if (error.empty()) { error = msg; first = true; } }
-    if (first && use_rccl) {
-      std::lock_guard<std::mutex> g(error_lock);
-      broken = true;
-      for (ncclComm_t& c : comms) if (c) { (void)rccl.CommAbort(c); c = nullptr; }
-    }
+    { std::lock_guard<std::mutex> g(error_lock); if (error.empty()) error = msg; }
+    failed.store(true);
     meet.abort();
   }
 };
@@ -121,6 +128,7 @@ namespace {
   } while (0)
 #define G_NCCL(expr)                                                                                      \
   do {                                                                                                    \
+    if (g->failed.load()) return false;             /* another rank failed: no further transfer is queued */ \
     ncclResult_t r_ = (expr);                                                                             \
     if (r_ != ncclSuccess) { g->fail(std::string(#expr) + ": " + g->rccl.GetErrorString(r_)); return false; } \
   } while (0)
@@ -135,6 +143,19 @@ size_t stripe_elems(int W, int H, int world, int rank) {
   return (size_t)ncols * 8 * (size_t)H * 3;
 }
 
+// waits until everything queued on `st` has run: a poll, so that the wait can end on a deadline or because another rank failed.
+// 0 = idle, 1 = gave up (deadline / failed flag), 2 = the stream reports an error
+int wait_stream(dr_group* g, hipStream_t st, std::chrono::steady_clock::time_point t_end, bool watch_failed, hipError_t* err) {
+  for (;;) {
+    const hipError_t q = hipStreamQuery(st);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) { if (err) *err = q; return 2; }
+    if (watch_failed && g->failed.load()) return 1;
+    if (std::chrono::steady_clock::now() > t_end) return 1;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 // one rank's share of dr_group_render_accumulate
 bool rank_work(dr_group* g, int r, const float* st, int W, int H, float bg, uint64_t seed, uint64_t stride, int nframes, int every) {
   G_HIP(hipSetDevice(g->device[(size_t)r]));
@@ -147,6 +168,8 @@ bool rank_work(dr_group* g, int r, const float* st, int W, int H, float bg, uint
   for (int k = 0; k < nframes; k += every, batch++) {
     const int n = nframes - k < every ? nframes - k : every;
     const int slot = batch & 1;
+    if (g->failed.load()) return false;
+    if (r == g->fail_rank && batch == g->fail_batch) { g->fail("rank " + std::to_string(r) + ": injected failure before batch " + std::to_string(batch)); return false; }
     if (batch >= 2) G_HIP(hipStreamWaitEvent(render, g->sent[slot][(size_t)r], 0));     // the slot's previous contents have left
     G_DR(dr_render_accumulate_async(c, st, W, H, bg, seed + (uint64_t)k * stride, stride, n));
     if (g->n == 1) continue;
@@ -162,12 +185,14 @@ bool rank_work(dr_group* g, int r, const float* st, int W, int H, float bg, uint
       if (r != 0 && bytes) G_HIP(hipMemcpyPeerAsync(stage + (size_t)r * g->stage_stride, g->device[0], pk, g->device[(size_t)r], bytes, comm));
       G_HIP(hipEventRecord(g->sent[slot][(size_t)r], comm));
       g->meet.arrive();                                        // every rank has recorded sent(batch)
+      if (g->failed.load()) return false;                      // (or was released because one of them failed)
       if (r == 0) {
         for (int q = 1; q < g->n; q++) G_HIP(hipStreamWaitEvent(comm, g->sent[slot][(size_t)q], 0));
         G_DR(dr_accum_unpack_stripes(c, stage, g->stage_stride * sizeof(int32_t), g->n, 1, comm));
         G_HIP(hipEventRecord(g->sent[slot][0], comm));
       }
       g->meet.arrive();                                        // nobody re-records an event rank 0 has not yet waited on
+      if (g->failed.load()) return false;
     } else {
       if (r != 0) {
         if (bytes) G_NCCL(g->rccl.Send(pk, bytes / sizeof(int32_t), ncclInt32, 0, g->comms[(size_t)r], comm));
@@ -183,18 +208,59 @@ bool rank_work(dr_group* g, int r, const float* st, int W, int H, float bg, uint
       G_HIP(hipEventRecord(g->sent[slot][(size_t)r], comm));
     }
   }
-  G_HIP(hipStreamSynchronize(comm));
-  G_DR(dr_context_synchronize(c));
+  // wait for both streams: a poll with a deadline, so that a transfer that is never matched (or a rank that failed) cannot hang the call
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(g->timeout_s));
+  for (hipStream_t st : {comm, render}) {
+    hipError_t err = hipSuccess;
+    const int w = wait_stream(g, st, t_end, true, &err);
+    if (w == 2) { g->fail(std::string("rank ") + std::to_string(r) + ": hipStreamQuery: " + hipGetErrorString(err)); return false; }
+    if (w == 1) {
+      if (!g->failed.load())
+        g->fail("rank " + std::to_string(r) + ": no end of the " + (st == comm ? "gather" : "rendering") + " of batch " + std::to_string(batch - 1) + " after " +
+                std::to_string((int)g->timeout_s) + " s (DOGERAY_GROUP_TIMEOUT_S)");
+      return false;
+    }
+  }
+  G_DR(dr_context_synchronize(c));      // (both streams are idle: this collects the batches' times)
   return true;
 }
 
+// every rank thread runs f(rank); returns when all have (true: all succeeded)
 bool for_all_ranks(dr_group* g, const std::function<bool(int)>& f) {
-  std::vector<std::thread> th;
-  std::vector<char> ok((size_t)g->n, 0);
-  for (int r = 0; r < g->n; r++) th.emplace_back([&, r] { ok[(size_t)r] = f(r) ? 1 : 0; });
-  for (std::thread& t : th) t.join();
-  for (char o : ok) if (!o) return false;
+  std::unique_lock<std::mutex> lk(g->job_lock);
+  g->job = f; g->job_left = g->n; g->job_ok.assign((size_t)g->n, 0); g->job_id++;
+  g->job_cv.notify_all();
+  g->done_cv.wait(lk, [&] { return g->job_left == 0; });
+  g->job = nullptr;
+  for (char o : g->job_ok) if (!o) return false;
   return true;
+}
+
+void rank_thread(dr_group* g, int r) {
+  (void)hipSetDevice(g->device[(size_t)r]);
+  unsigned long seen = 0;
+  for (;;) {
+    std::function<bool(int)> f;
+    {
+      std::unique_lock<std::mutex> lk(g->job_lock);
+      g->job_cv.wait(lk, [&] { return g->quit || g->job_id != seen; });
+      if (g->quit) return;
+      seen = g->job_id; f = g->job;
+    }
+    const bool ok = f(r);
+    {
+      std::lock_guard<std::mutex> lk(g->job_lock);
+      g->job_ok[(size_t)r] = ok ? 1 : 0;
+      if (--g->job_left == 0) g->done_cv.notify_all();
+    }
+  }
+}
+
+// after a failed render call, when every rank thread has returned: cancel what RCCL still has queued (transfers that will never be matched)
+void abort_communicators(dr_group* g) {
+  if (!g->use_rccl) return;
+  for (ncclComm_t& c : g->comms) if (c) { (void)g->rccl.CommAbort(c); c = nullptr; }
+  g->broken = true;
 }
 
 }  // namespace
@@ -217,6 +283,9 @@ int dr_group_create(int n, const int* device_ordinals, dr_group** out) {
     g->device.push_back(device_ordinals ? device_ordinals[r] : (r < (int)env_dev.size() ? env_dev[(size_t)r] : r));
     for (int q = 0; q < r; q++) if (g->device[(size_t)q] == g->device[(size_t)r]) distinct = false;
   }
+  if (const char* e = getenv("DOGERAY_GROUP_TIMEOUT_S")) { const double v = atof(e); if (v > 0) g->timeout_s = v; }
+  if (const char* e = getenv("DOGERAY_GROUP_FAIL_RANK")) g->fail_rank = atoi(e);
+  if (const char* e = getenv("DOGERAY_GROUP_FAIL_BATCH")) g->fail_batch = atoi(e);
   const char* tr = getenv("DOGERAY_GROUP_TRANSPORT");
   // DOGERAY_GROUP_TRANSPORT=copy: peer copies even between distinct devices; =rccl: RCCL even for one rank (rehearsal: loads the
   // library, creates the communicator and sends a buffer to itself, which is all a one-GPU box allows)
@@ -265,12 +334,16 @@ int dr_group_create(int n, const int* device_ordinals, dr_group** out) {
       (void)hipDeviceEnablePeerAccess(g->device[0], 0);
     }
   }
+  for (int r = 0; r < n; r++) g->threads.emplace_back(rank_thread, g, r);
   *out = g;
   return DR_OK;
 }
 
 void dr_group_destroy(dr_group* g) {
   if (!g) return;
+  { std::lock_guard<std::mutex> lk(g->job_lock); g->quit = true; }
+  g->job_cv.notify_all();
+  for (std::thread& t : g->threads) t.join();
   for (ncclComm_t c : g->comms) if (c) (void)g->rccl.CommDestroy(c);
   for (int r = 0; r < g->n; r++) {
     if (r < (int)g->device.size()) (void)hipSetDevice(g->device[(size_t)r]);
@@ -299,12 +372,12 @@ int dr_group_rccl_ranks(const dr_group* g) {
 int dr_group_upload_scene(dr_group* g, const dr_scene* s) {
   if (!g || !s) { set_error("null argument"); return DR_ERR_INVALID; }
   if (g->broken) { set_error("group: unusable after a failed call (its RCCL communicators were aborted); destroy it"); return DR_ERR_DEVICE; }
-  g->error.clear();
+  g->error.clear(); g->failed.store(false);
   const bool ok = for_all_ranks(g, [&](int r) {
     if (dr_context_upload_scene(g->ctx[(size_t)r], s) != DR_OK) { g->fail(std::string("upload on rank ") + std::to_string(r) + ": " + dr_last_error()); return false; }
     return true;
   });
-  if (!ok) { set_error(g->error); return DR_ERR_DEVICE; }
+  if (!ok) { set_error(g->error); return DR_ERR_DEVICE; }      // (nothing was in flight between the ranks: the group stays usable)
   return DR_OK;
 }
 
@@ -335,10 +408,23 @@ int dr_group_render_accumulate(dr_group* g, const float settings13[13], int W, i
   if (g->broken) { set_error("group: unusable after a failed call (its RCCL communicators were aborted); destroy it"); return DR_ERR_DEVICE; }
   if (nframes == 0) return DR_OK;
   const int every = gather_every > 0 ? gather_every : nframes;
-  g->error.clear();
+  g->error.clear(); g->failed.store(false);
   g->meet.aborted = false; g->meet.waiting = 0;
   const bool ok = for_all_ranks(g, [&](int r) { return rank_work(g, r, settings13, W, H, background, frame_seed, seed_stride, nframes, every); });
-  if (!ok) { set_error("group: " + g->error); return DR_ERR_DEVICE; }
+  if (!ok) {
+    abort_communicators(g);      // every rank thread is back: nobody is inside RCCL
+    // what the ranks had queued may still be running: wait for it (bounded: a kernel ends, an aborted transfer is gone) before the caller touches anything
+    const auto t_end = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(g->timeout_s));
+    for (int r = 0; r < g->n; r++) {
+      (void)hipSetDevice(g->device[(size_t)r]);
+      hipStream_t render = nullptr;
+      (void)dr_context_stream(g->ctx[(size_t)r], (void**)&render);
+      if (wait_stream(g, g->comm[(size_t)r], t_end, false, nullptr) == 0 && wait_stream(g, render, t_end, false, nullptr) == 0) (void)dr_context_synchronize(g->ctx[(size_t)r]);
+      else g->broken = true;      // (still busy after the deadline: nothing more can be done with this group but destroying it)
+    }
+    set_error("group: " + g->error);
+    return DR_ERR_DEVICE;
+  }
   return DR_OK;
 }
 

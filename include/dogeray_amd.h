@@ -178,6 +178,8 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   help with their rays from the first step
  *                   Threaded walk ("coop_steps" again): once the queue is empty, a ray older than that is finished by all 64
  *                   lanes breadth-first, in waves with at most "coop_lanes" (8) lanes walking
+ *   "reserve_cus"   persistent kernel: workgroups are launched for this many CUs fewer than the device has (0 = all; dr_group ranks may leave
+ *                   room for the gather's copy / RCCL kernels beside the next batch's rendering)
  *   "wave_log"      1: short launches record begin / queue empty / end of every wave (dr_stats_wave_log)
  *   "wide_tree"     tree under the wide walk, read at dr_context_upload_scene: 1 (default) binned surface-area
  *                   heuristic over the leaf boxes, 0 the reference's own topology (K:1745-1861) collapsed 4-way

@@ -107,6 +107,46 @@ def test_group_on_one_device_assembles_the_frame(dr, scene, ranks, every):
     g.close()
 
 
+def test_group_failure_returns_an_error_and_destroys_cleanly(dr, scene, monkeypatch):
+    """A rank that fails in the middle of a render call (injected: DOGERAY_GROUP_FAIL_RANK / _BATCH): the call returns an error -- no hang: the other
+    ranks are released from the rendezvous, stream waits are polls with a deadline -- and the group is destroyed cleanly.  Copy transport with three ranks
+    on this device (the group stays usable), and the one-rank RCCL rehearsal (the communicator is aborted by the coordinator once every rank thread is
+    back: the group says it is unusable)."""
+    import time
+    s = scene.settings()
+    st = dr.pack_settings13(s, 1)
+    monkeypatch.setenv("DOGERAY_GROUP_TIMEOUT_S", "20")
+    monkeypatch.setenv("DOGERAY_GROUP_FAIL_RANK", "1")
+    monkeypatch.setenv("DOGERAY_GROUP_FAIL_BATCH", "1")
+    g = dr.Group([0, 0, 0]).upload(scene)
+    g.accum_reset(W, H)
+    t0 = time.time()
+    with pytest.raises(dr.DogerayError, match="injected failure"):
+        g.render_accumulate(st, W, H, s.background, 31, 1000003, 6, gather_every=2)
+    assert time.time() - t0 < 15
+    g.close()
+    # without the injection the same group shape works (the environment is read when a group is created)
+    monkeypatch.delenv("DOGERAY_GROUP_FAIL_RANK"); monkeypatch.delenv("DOGERAY_GROUP_FAIL_BATCH")
+    g = dr.Group([0, 0, 0]).upload(scene)
+    g.accum_reset(W, H)
+    g.render_accumulate(st, W, H, s.background, 31, 1000003, 6, gather_every=2)
+    g.close()
+    # one rank on RCCL
+    monkeypatch.setenv("DOGERAY_GROUP_TRANSPORT", "rccl")
+    monkeypatch.setenv("DOGERAY_GROUP_FAIL_RANK", "0")
+    monkeypatch.setenv("DOGERAY_GROUP_FAIL_BATCH", "1")
+    g = dr.Group([0]).upload(scene)
+    assert g.uses_rccl and g.rccl_ranks == 1
+    g.accum_reset(W, H)
+    t0 = time.time()
+    with pytest.raises(dr.DogerayError, match="injected failure"):
+        g.render_accumulate(st, W, H, s.background, 31, 1000003, 6, gather_every=2)
+    assert time.time() - t0 < 15
+    with pytest.raises(dr.DogerayError, match="unusable"):
+        g.render_accumulate(st, W, H, s.background, 31, 1000003, 2, gather_every=2)
+    g.close()
+
+
 def test_native_host_application_with_gpus(dr, synth, tmp_path):
     """csrc/dogeray_main.cpp --gpus 3 (three ranks on this GPU): the image equals the one-GPU run's."""
     exe = os.path.join(ROOT, "dogeray_amd", "bin", "dogeray")
