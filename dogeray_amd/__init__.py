@@ -124,6 +124,7 @@ _API = [
     ("dr_stats_enable_counters", C.c_int, [_VP, C.c_int]),
     ("dr_stats_reset", C.c_int, [_VP]),
     ("dr_stats_get", C.c_int, [_VP, C.POINTER(DrStats)]),
+    ("dr_stats_phase_counts", C.c_int, [_VP, C.POINTER(C.c_ulonglong), C.c_int]),
     ("dr_stats_wave_log", C.c_int, [_VP, C.POINTER(C.c_ulonglong), C.c_int, C.POINTER(C.c_int)]),
     ("dr_stats_pixel_cost", C.c_int, [_VP, C.POINTER(C.c_uint), C.c_size_t, C.POINTER(C.c_size_t)]),
     ("dr_context_probe_gather", C.c_int, [_VP, C.c_uint32, C.c_int, C.POINTER(C.c_double)]),
@@ -421,6 +422,12 @@ class Context:
         s = DrStats()
         _check(lib().dr_stats_get(self._h, C.byref(s)))
         return s.as_dict()
+
+    def phase_counts(self, n=32):
+        """The shade / refill phase's budget counters of the counting build (dr_stats_phase_counts)."""
+        buf = (C.c_ulonglong * n)()
+        _check(lib().dr_stats_phase_counts(self._h, buf, n))
+        return [int(v) for v in buf]
 
     def wave_log(self, max_waves=16384):
         """(n, 16) uint64: begin, queue-empty, end stamps (100 MHz ticks) and iterations after the queue was empty, per wave of the

@@ -901,6 +901,14 @@ int dr_stats_get(dr_context* c, dr_stats* out) {
   return DR_OK;
 }
 
+int dr_stats_phase_counts(dr_context* c, unsigned long long* out, int n) {
+  if (!c || !out || n < 0 || n > COUNTER_WORDS - 16) { set_error("bad argument"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (n > 0) HIP_TRY(hipMemcpy(out, c->counters + 16, (size_t)n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  return DR_OK;
+}
+
 int dr_stats_wave_log(dr_context* c, unsigned long long* out, int max_waves, int* n_waves) {
   if (!c || !out || !n_waves || max_waves < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
   if (!c->wave_log) { set_error("wave log is off (option wave_log)"); return DR_ERR_INVALID; }

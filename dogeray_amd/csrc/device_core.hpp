@@ -83,7 +83,7 @@ struct Xorwow {
   __device__ __forceinline__ uint32_t next() {
     uint32_t t = v0 ^ (v0 >> 2);
     v0 = v1; v1 = v2; v2 = v3; v3 = v4;
-    v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1));
+    v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1));      // (the compiler already folds three of the four terms into one v_bitop3_b32; spelling t << 1 as t + t changes nothing, it turns it back into a shift)
     d += 362437u;
     return v4 + d;
   }
@@ -150,10 +150,14 @@ __device__ __forceinline__ V3 rand_in_unit_disk(Xorwow& r) {     // K:988-994
 // lanes with kind 2 a point in the unit disk (K:988-994: two uniforms per candidate, in float), lanes with kind 0 nothing -- each lane's sequence of
 // draws is exactly that of rand_in_unit_sphere / rand_in_unit_disk, but the wave runs the loop once, for as many turns as its unluckiest lane needs,
 // instead of once per kind (the persistent kernel's shade / refill phase: the lanes that scatter and the lanes that start a path).
-__device__ __forceinline__ V3 rand_points_merged(Xorwow& r, int kind) {
+// (turns: counting builds only -- the number of candidates this lane drew; the wave runs the loop for as many turns as its unluckiest lane)
+template <bool COUNT = false>
+__device__ __forceinline__ V3 rand_points_merged(Xorwow& r, int kind, unsigned* turns = nullptr) {
   V3 p = mk(0, 0, 0);
   bool todo = kind != 0;
   while (todo) {
+    DR_MARK("reject_turn");
+    if (COUNT) (*turns)++;
     const double zx = r.z_plus_half(), zy = r.z_plus_half();
     float x, y, z = 0.0f;
     if (kind == 3) {
@@ -165,6 +169,7 @@ __device__ __forceinline__ V3 rand_points_merged(Xorwow& r, int kind) {
     p = mk(x, y, z);
     todo = outside_unit(dot(p, p));
   }
+  DR_MARK("reject_done");
   return p;
 }
 
@@ -698,6 +703,21 @@ __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, 
   if (COUNT) c.V++;
   float mn[3] = {f(r.A.x), f(r.A.y), f(r.A.z)}, mx[3] = {f(r.B.x), f(r.B.y), f(r.B.z)};
   float dist;
+#ifndef DR_HOST_BUILD
+  if (!COUNT) {
+    // The candidate is accepted when its primitive is hit AND the leaf's box is entered no farther than the best t (hit() K:484-488: box, then primitive):
+    // a conjunction of pure tests, so the order is free.  The primitive first, for every lane (98 % of the lanes pass the box anyway); the box only for the
+    // lanes whose primitive is a candidate -- 5 % of them --, and not at all when no lane of the wave has one: 0.5721 against 0.5777 ms/frame
+    // (profiles/r4_e_phase_budget.txt).  The counting build and the host build keep the reference's order: L counts primitives tested behind a passed box.
+    const int info = (int)r.A.w;
+    const float t = prim_hit_kind((info >> WALK_SLOT_BITS) & 3, mk(f(r.B.w), f(r.C.x), f(r.C.y)), mk(f(r.C.z), f(r.C.w), f(r.D.x)), mk(f(r.D.y), f(r.D.z), f(r.D.w)), o, d);
+    const int slot = info & ((1 << WALK_SLOT_BITS) - 1);
+    const bool cand = t > 0.0f && (t < tr.best_t || (t == tr.best_t && (unsigned)slot < (unsigned)tr.best_slot));
+    if (__builtin_amdgcn_ballot_w64(cand) != 0ull) {
+      if (cand && slab_sel(o, inv, sg, mn, mx, dist) && dist <= tr.best_t) { tr.best_t = t; tr.best_slot = slot; }
+    }
+  } else
+#endif
   if (slab_sel(o, inv, sg, mn, mx, dist) && dist <= tr.best_t) {      // <=: a box entered exactly at the best t may hold a tie with a lower slot
     if (COUNT) c.L++;
     const int info = (int)r.A.w;

@@ -31,7 +31,7 @@ void launch_tile_kernel(hipStream_t stream, const RenderParams& P, int traversal
 int launch_persistent_kernel(hipStream_t stream, const RenderParams& P, const PersistentCfg& cfg, unsigned* tile_counter, const int* order,
                              const int* region_start, unsigned* pixel_cost);
 
-constexpr int COUNTER_WORDS = 16;   // 64-bit words of a context's statistics buffer: [0, 8) ray counters, [8, 16) dr_stats.diag
+constexpr int COUNTER_WORDS = 48;   // 64-bit words of a context's statistics buffer: [0, 8) ray counters, [8, 16) dr_stats.diag, [16, 48) the shade / refill phase's budget (dr_stats_phase_counts)
 
 // kernels_aux.hip
 void launch_tile_feedback(hipStream_t stream, const unsigned* pixel_cost, unsigned* tile_cost, int* tile_order, int* region_start, int tiles, int regions,

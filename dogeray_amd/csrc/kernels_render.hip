@@ -360,7 +360,25 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
       }
       {
         // ---- the phase's rejection loop, once for the wave: sphere points for the lanes that scatter, disk points for the lanes that start a path
-        const V3 pt = rand_points_merged(rng, scatter_me && shade_needs_sphere(sc) ? 3 : (new_path ? 2 : 0));
+        unsigned my_turns = 0;
+        const int draw_kind = scatter_me && shade_needs_sphere(sc) ? 3 : (new_path ? 2 : 0);
+        const V3 pt = rand_points_merged<COUNT>(rng, draw_kind, &my_turns);
+        if (COUNT) {
+          // the phase's budget (dr_stats_phase_counts): how many turns the wave's rejection loop ran (= its unluckiest lane's), how many lane-turns were useful
+          unsigned wave_turns = my_turns;
+          for (int off = 32; off > 0; off >>= 1) { const unsigned o = (unsigned)__shfl_xor((int)wave_turns, off, 64); wave_turns = o > wave_turns ? o : wave_turns; }
+          unsigned long long lane_turns = my_turns;
+          for (int off = 32; off > 0; off >>= 1) lane_turns += __shfl_xor(lane_turns, off, 64);
+          const unsigned n_sphere = (unsigned)__popcll(__ballot(draw_kind == 3)), n_disk = (unsigned)__popcll(__ballot(draw_kind == 2));
+          if (lane == 0) {
+            atomicAdd(&P.counters[16 + (wave_turns < 15u ? wave_turns : 15u)], 1ull);      // histogram of turns per phase
+            atomicAdd(&P.counters[32], lane_turns);                                        // candidates drawn by all lanes
+            atomicAdd(&P.counters[33], (unsigned long long)wave_turns);                    // turns the waves ran
+            atomicAdd(&P.counters[34], (unsigned long long)n_sphere);                      // lanes that drew a point in the sphere (scatter)
+            atomicAdd(&P.counters[35], (unsigned long long)n_disk);                        // lanes that drew a point in the disk (new path)
+            atomicAdd(&P.counters[36], (unsigned long long)__popcll(__ballot(tr.node == -3)));   // retired lanes at the phase
+          }
+        }
         if (scatter_me) shade_scatter(path, sc, pt, rng);
         if (new_path) {
           camera_finish(P, cam_nu, cam_nv, pt, path.rayo, path.raydir);

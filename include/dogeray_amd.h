@@ -295,6 +295,12 @@ int dr_stats_enable_counters(dr_context* c, int on); /* counting build of the ke
 int dr_stats_reset(dr_context* c);
 int dr_stats_get(dr_context* c, dr_stats* out);
 
+/* Counting build of the persistent kernel (dr_stats_enable_counters): the shade / refill phase's budget since dr_stats_reset, n <= 32 words:
+ * [0..15] histogram of the turns a wave's rejection loop ran in a phase (bin 15: 15 or more; bin 0: nobody drew), [16] candidates drawn by all lanes,
+ * [17] turns summed over phases, [18] lanes that drew a point in the unit sphere (scatter, K:640-648), [19] lanes that drew a point in the unit disk
+ * (new path, K:988-994), [20] retired lanes summed over phases.  With dr_stats.diag (phases, lanes shaded, cycles in phases) this prices the phase. */
+int dr_stats_phase_counts(dr_context* c, unsigned long long* out, int n);
+
 /* Timeline of the last SHORT persistent-kernel launch (fewer than coop_tiles_per_wave tiles per wave: one frame, a thin stripe;
  * option "wave_log" = 1 before the launch): sixteen words per wave --
  * begin, first time the wave found the work queue empty (0: never), end, all in 100 MHz ticks of the GPU's
