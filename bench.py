@@ -126,7 +126,11 @@ def measure_counters(args):
     out = {}
     tmp = tempfile.mkdtemp(prefix="dogeray_pmc_")
     try:
-        for group in (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVES"]):
+        groups = (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_WAVES"],
+                  # the instruction classes gfx950's SQ counts separately (round 4): what the issue slots are spent on
+                  ["SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_TRANS_F32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32"],
+                  ["SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_INT64", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"])
+        for gi, group in enumerate(groups):
             d = os.path.join(tmp, group[0])
             cmd = [prof, "--pmc"] + group + ["-d", d, "-o", "pmc", "--output-format", "csv", "--", sys.executable, os.path.abspath(__file__),
                    "--config", args.config, "--steps", str(args.steps), "--warmup", str(max(args.warmup, args.steps)), "--batch", str(args.batch), "--traversal", args.traversal,
@@ -135,6 +139,9 @@ def measure_counters(args):
             env = dict(os.environ, TMPDIR="/tmp")
             r = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, env=env, cwd="/tmp")
             if r.returncode != 0:
+                if gi >= 3:                               # the class counters are an extra: without them the roofline stands as before
+                    out.setdefault("unavailable", []).extend(group)
+                    continue
                 return None
             vals = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -145,6 +152,9 @@ def measure_counters(args):
             for name in group:
                 v = vals.get(name)
                 if not v:
+                    if gi >= 3:
+                        out.setdefault("unavailable", []).append(name)
+                        continue
                     return None
                 full = max(v)                         # launches that cover a full batch report the largest value
                 v = [x for x in v if x > 0.8 * full]
@@ -433,7 +443,7 @@ def main():
         # the same one-frame launches through the pipeline (frame k + 1 starts while frame k drains; per-frame buffers added in order),
         # without and with the display divide + download of every frame (what an interactive viewer pays)
         try:
-            n2 = max(n1, 32)
+            n2 = max(n1, 64)
             ctx._acc_shape = (W, H, 3)
             ctx.render_accumulate_pipelined(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, 8)
             walls = []
@@ -443,11 +453,23 @@ def main():
                 ctx.render_accumulate_pipelined(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, n2)
                 walls.append((time.perf_counter() - t0) / n2 * 1e3)
             single["pipelined_wall_ms"] = sorted(walls)[1]
+            single["pipe_group"] = ctx.get_option("pipe_group")
+            # ... and with a launch per frame (pipe_group 1: round 3's pipeline, two launches side by side)
+            ctx.set_option("pipe_group", 1)
+            walls = []
+            for rep in range(3):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ctx.render_accumulate_pipelined(st, W, H, s.background, seed_base + args.warmup * seed_stride, seed_stride, n2)
+                walls.append((time.perf_counter() - t0) / n2 * 1e3)
+            single["pipelined_group1_wall_ms"] = sorted(walls)[1]
+            ctx.set_option("pipe_group", single["pipe_group"])
             t0 = time.perf_counter()
             pend = []
+            window = 2 * max(1, single["pipe_group"])
             for k in range(n2):
                 pend.append(ctx.pipeline_submit(st, W, H, s.background, seed_base + (args.warmup + k) * seed_stride, k + 1))
-                if len(pend) == 2:
+                if len(pend) == window:
                     ctx.pipeline_wait(pend.pop(0), want_image=True, in_place=True)
             for t in pend:
                 ctx.pipeline_wait(t, want_image=True, in_place=True)
@@ -528,6 +550,7 @@ def main():
         "ms_per_step_max": max(region_s) / frames * 1e3,
         "single_frame_ms": single["kernel_ms"] if single else None,
         "single_frame_pipelined_ms": single.get("pipelined_wall_ms") if single else None,
+        "single_frame_pipelined_group1_ms": single.get("pipelined_group1_wall_ms") if single else None,
         "single_frame": single,
         "rays_per_frame": rays / frames,
         "primary_samples_per_s": (W * H * frames) / elapsed,
@@ -581,11 +604,6 @@ def main():
         rf["achieved"] = lane_ops / 1e12
         rf["frac"] = lane_ops / VALU_PEAK_LANE_OPS
         rf["traffic"] = t["bytes_per_launch"]
-        # `frac` does not rise when work is removed (fewer instructions per ray lower lane_ops and launch_ms together).  For a number that moves with
-        # the rate: the rays per second of this run times the active-lane operations ROUND 2's kernel spent per ray (159.8 wave-level instructions
-        # x 64 lanes x 0.359 lane use, profiles/r2_b), over the same peak -- 0.245 in round 2 (C4 only: the constant is that scene's)
-        if args.config == "C4":
-            rf["frac_at_round2_work"] = (rays / frames * frames_per_launch) / (launch_ms * 1e-3) * (159.8 * 64 * 0.359) / VALU_PEAK_LANE_OPS
         rf["valu"] = {"wave_instructions_per_launch": t["SQ_INSTS_VALU"], "active_lane_ops_per_launch": t["SQ_THREAD_CYCLES_VALU"],
                       "lane_use": t["SQ_THREAD_CYCLES_VALU"] / (64.0 * t["SQ_INSTS_VALU"]),
                       "issue_busy_frac_at_2_cycles_per_instruction": t["SQ_INSTS_VALU"] * 2.0 / (1024 * 2.4e9 * launch_ms * 1e-3),
@@ -594,6 +612,26 @@ def main():
                                          "fma_mix, perm, every f64 operation), 8.2 (rcp, sqrt); the classes overlap partly",
                       "wave_instructions_per_ray": t["SQ_INSTS_VALU"] / (rays / frames * frames_per_launch),
                       "salu_per_launch": t["SQ_INSTS_SALU"], "vmem_rd_per_launch": t["SQ_INSTS_VMEM_RD"]}
+        # How close to the issue limit: the SQ's per-class instruction counts priced with the measured issue cost of each class (tools/valu_rate.hip: 2.4 SIMD
+        # cycles for fma / add / mul f32, 8.2 for rcp / sqrt, 4.2 for conversions and every f64 operation), over the SIMD cycles of the launch.  The SQ does not
+        # split the integer / logic / compare / select / move instructions (INT32 and the unnamed rest) into the 2.4- and the 4.2-cycle members of that group, so
+        # the fraction comes as a pair: all of them at 2.4 (low) and all at 4.2 (high); the static ISA has them about half and half (tools/isa_cost.py).
+        cls = {k: t[k] for k in t if k.startswith("SQ_INSTS_VALU_")}
+        if cls and "SQ_INSTS_VALU_INT32" in cls:
+            simd_cycles = 1024 * 2.4e9 * launch_ms * 1e-3
+            fast = cls.get("SQ_INSTS_VALU_FMA_F32", 0) + cls.get("SQ_INSTS_VALU_ADD_F32", 0) + cls.get("SQ_INSTS_VALU_MUL_F32", 0)
+            trans = cls.get("SQ_INSTS_VALU_TRANS_F32", 0)
+            slow = cls.get("SQ_INSTS_VALU_CVT", 0) + cls.get("SQ_INSTS_VALU_FMA_F64", 0) + cls.get("SQ_INSTS_VALU_ADD_F64", 0) + cls.get("SQ_INSTS_VALU_MUL_F64", 0)
+            mixed = max(0.0, t["SQ_INSTS_VALU"] - fast - trans - slow)      # INT32, INT64, compares, selects, moves, min / max ...
+            rf["valu"]["classes_per_launch"] = dict(cls, other=mixed - cls.get("SQ_INSTS_VALU_INT32", 0) - cls.get("SQ_INSTS_VALU_INT64", 0))
+            rf["valu"]["issue_priced_frac_low"] = (2.4 * fast + 8.2 * trans + 4.2 * slow + 2.4 * mixed) / simd_cycles
+            rf["valu"]["issue_priced_frac_high"] = (2.4 * fast + 8.2 * trans + 4.2 * slow + 4.2 * mixed) / simd_cycles
+            rf["valu"]["issue_priced_frac"] = (2.4 * fast + 8.2 * trans + 4.2 * slow + 3.3 * mixed) / simd_cycles
+            for k in ("SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES"):
+                if k in t:
+                    rf["valu"][k.lower() + "_per_launch"] = t[k]
+        if t.get("unavailable"):
+            rf["valu"]["counters_unavailable"] = t["unavailable"]
         hbm_gbs = t["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
         rf["hbm"] = {"achieved_GBs": hbm_gbs, "peak_GBs": HBM_PEAK_GBS, "frac": hbm_gbs / HBM_PEAK_GBS,
                      "note": "rocprofv3 PMC, separate passes, per launch of the timed kernel: 2 x FETCH_SIZE (%.3g B raw; gfx950 reports half of 16-B/lane reads) "

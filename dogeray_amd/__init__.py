@@ -354,7 +354,7 @@ class Context:
 
     def pipeline_wait(self, ticket, want_image=False, in_place=False):
         """Waits for a submitted frame; with want_image the RGB8 image [H, W, 3] of exactly the frames up to that ticket (in_place: a
-        read-only view of the library's pinned download buffer, valid until pipe_streams + 1 more frames have been submitted)."""
+        read-only view of the library's pinned download buffer, valid until pipe_streams + 1 more GROUPS of frames have been launched)."""
         if not want_image:
             _check(lib().dr_pipeline_wait(self._h, int(ticket), None))
             return None
@@ -622,21 +622,23 @@ class ProgressiveRenderer:
     def image(self, divide_by):
         return self.ctx.accum_present(divide_by)
 
-    def run_pipelined(self, nframes, on_image=None):
-        """The accumulating part of the loop (iter >= 4), `nframes` frames, pipelined (dr_pipeline_submit / dr_pipeline_wait): frame k + 1
-        is queued before frame k's image is waited for.  on_image(iter, divide_by, rgb[H, W, 3]) gets every displayed image, each exactly
-        clamp(sum of the frames so far / divide_by, 0, 255)."""
+    def run_pipelined(self, nframes, on_image=None, in_flight=None):
+        """The accumulating part of the loop (iter >= 4), `nframes` frames, pipelined (dr_pipeline_submit / dr_pipeline_wait): up to `in_flight` frames
+        (default: two groups, 2 x option pipe_group) are queued before the oldest one's image is waited for.  on_image(iter, divide_by, rgb[H, W, 3])
+        gets every displayed image, each exactly clamp(sum of the frames so far / divide_by, 0, 255)."""
         assert self.iter >= 4, "run the preview ladder (four step() calls) first"
         s, c = self.s, self.ctx
         c._acc_shape = (self.W, self.H, 3)
         st = pack_settings13(s, 1)
+        if in_flight is None:
+            in_flight = 2 * max(1, c.get_option("pipe_group"))
         pending = []
         for k in range(nframes):
             self.iter += 1
             div = self.iter - 3
             pending.append((c.pipeline_submit(st, self.W, self.H, s.background, self._seed(), div), self.iter, div))
             self.frames_rendered += 1
-            if len(pending) == 2:
+            if len(pending) >= in_flight:
                 t, it, dv = pending.pop(0)
                 img = c.pipeline_wait(t, want_image=True)
                 if on_image:

@@ -82,13 +82,25 @@ struct dr_context {
   int pipe_streams = 2;     // render streams the pipeline alternates between
   int pipe_lean = 0;        // pipelined launches run the lean build with one queue per XCD instead of the work-sharing build (their tails overlap other frames)
   hipStream_t pipe_stream[PIPE_STREAMS] = {nullptr, nullptr, nullptr, nullptr}, acc_stream = nullptr;      // pipe_stream[0] = stream
-  int32_t* pipe_frame[PIPE_DEPTH] = {nullptr}; size_t pipe_elems[PIPE_DEPTH] = {0};
-  int pipe_rect[PIPE_DEPTH][6] = {{0}};            // W, H, gx, gy, stripe mod, stripe rem the buffer was last rendered with (its margins are 0)
-  hipEvent_t pipe_rendered[PIPE_DEPTH] = {nullptr}, pipe_added[PIPE_DEPTH] = {nullptr};
-  uint8_t* pipe_rgb_dev[PIPE_DEPTH] = {nullptr}; uint8_t* pipe_rgb_host[PIPE_DEPTH] = {nullptr};
-  size_t pipe_rgb_bytes[PIPE_DEPTH] = {0};
-  int pipe_div[PIPE_DEPTH] = {0};                  // divisor the slot's frame was presented with (0: not presented)
-  bool pipe_waited[PIPE_DEPTH] = {true, true, true, true, true};
+  // a slot = one GROUP of frames in flight: frames submitted one after the other (same view, seeds in arithmetic progression) share one launch -- each
+  // rendered into a buffer of its own -- and are added to the accumulator and presented one by one, in ticket order (option pipe_group; 1 = a launch per frame)
+  static constexpr int PIPE_GROUP_MAX = 16;
+  struct PipeSlot {
+    int32_t* frames = nullptr; size_t elems_each = 0; int cap_frames = 0;      // cap_frames buffers of elems_each int32, one after the other
+    int rect[6] = {-1, 0, 0, 0, 0, 0};             // W, H, gx, gy, stripe mod, stripe rem the buffers were last rendered with (their margins are 0)
+    hipEvent_t rendered = nullptr;                 // end of the group's launch
+    hipEvent_t added[PIPE_GROUP_MAX] = {nullptr};  // frame f of the group has been added (and presented)
+    uint8_t* rgb_dev[PIPE_GROUP_MAX] = {nullptr}; uint8_t* rgb_host[PIPE_GROUP_MAX] = {nullptr}; size_t rgb_bytes[PIPE_GROUP_MAX] = {0};
+    int div[PIPE_GROUP_MAX] = {0};                 // divisor frame f was presented with (0: not presented)
+    bool fwaited[PIPE_GROUP_MAX] = {false};        // dr_pipeline_wait has returned for frame f
+    uint64_t first = 0; int count = 0;             // tickets [first, first + count)
+    bool drained = true;                           // the host has waited for the group's last add: its buffers may be reused at once
+  };
+  PipeSlot pipe_slot[PIPE_DEPTH];
+  uint64_t pipe_groups = 0;                        // groups launched so far (slot = group % (streams + 1), render stream = group % streams)
+  int pipe_group = 8;                              // most frames per group
+  struct PipePending { float st[13]; int W, H; float bg; uint64_t seed; int div; };
+  std::vector<PipePending> pipe_pending;           // submitted, not launched yet: tickets [pipe_next - size, pipe_next)
   uint64_t pipe_next = 0;                          // ticket of the next frame
   hipEvent_t pipe_last[PIPE_STREAMS] = {nullptr, nullptr, nullptr, nullptr};    // end of the newest launch on each render stream
   bool pipe_last_set[PIPE_STREAMS] = {false, false, false, false};
@@ -262,11 +274,12 @@ int set_option(dr_context* c, const std::string& name, int v) {
     if (v < 2 || v > dr_context::PIPE_STREAMS) goto bad;
     if (v != c->pipe_streams) {               // slots and streams are numbered by ticket: drain, then start again from ticket 0
       if (hipSetDevice(c->device) != hipSuccess || join_pipeline(c) != DR_OK || hipStreamSynchronize(c->stream) != hipSuccess) { set_error("pipe_streams: cannot drain the pipeline"); return DR_ERR_DEVICE; }
-      for (int k = 0; k < dr_context::PIPE_DEPTH; k++) c->pipe_waited[k] = true;
-      c->pipe_next = 0; c->pipe_streams = v;
+      for (int k = 0; k < dr_context::PIPE_DEPTH; k++) { c->pipe_slot[k].drained = true; c->pipe_slot[k].count = 0; }
+      c->pipe_next = 0; c->pipe_groups = 0; c->pipe_streams = v;
     }
   }
   else if (name == "pipe_lean") { c->pipe_lean = v != 0; }
+  else if (name == "pipe_group") { if (v < 1 || v > dr_context::PIPE_GROUP_MAX) goto bad; c->pipe_group = v; }
   else if (name == "xcd_regions") { c->xcd_regions = v != 0; c->order_valid = false; }
   else if (name == "batch_frames") { if (v < 1 || v > 256) goto bad; c->batch_frames = v; }
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
@@ -301,10 +314,14 @@ int collect_time(dr_context* c, uint64_t frames, uint64_t samples) {
 }
 
 // Work queued through the pipeline runs on two more streams: everything else (which uses `stream`) is ordered behind it here.
+int pipeline_flush(dr_context* c);
 int join_pipeline(dr_context* c) {
+  if (!c->pipe_pending.empty()) { const int rc = pipeline_flush(c); if (rc != DR_OK) return rc; }
   if (!c->pipe_dirty) return DR_OK;
-  for (int k = 0; k < dr_context::PIPE_DEPTH; k++)
-    if (c->pipe_added[k]) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_added[k], 0));
+  for (int k = 0; k < dr_context::PIPE_DEPTH; k++) {
+    const dr_context::PipeSlot& sl = c->pipe_slot[k];
+    if (sl.count > 0) HIP_TRY(hipStreamWaitEvent(c->stream, sl.added[sl.count - 1], 0));      // (adds run in order: the last one ends the group)
+  }
   for (int k = 1; k < dr_context::PIPE_STREAMS; k++) if (c->pipe_last_set[k]) HIP_TRY(hipStreamWaitEvent(c->stream, c->pipe_last[k], 0));
   c->pipe_dirty = false;
   return DR_OK;
@@ -318,7 +335,10 @@ int pipeline_setup(dr_context* c) {
   for (int k = 1; k < dr_context::PIPE_STREAMS; k++) ok = ok && (c->pipe_stream[k] || hipStreamCreateWithFlags(&c->pipe_stream[k], hipStreamNonBlocking) == hipSuccess);
   if (!ok) { set_error("pipeline: cannot create streams"); return DR_ERR_DEVICE; }
   auto event = [](hipEvent_t& e) { return e || hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess; };
-  for (int k = 0; k < dr_context::PIPE_DEPTH; k++) ok = ok && event(c->pipe_rendered[k]) && event(c->pipe_added[k]);
+  for (int k = 0; k < dr_context::PIPE_DEPTH; k++) {
+    ok = ok && event(c->pipe_slot[k].rendered);
+    for (int f = 0; f < dr_context::PIPE_GROUP_MAX; f++) ok = ok && event(c->pipe_slot[k].added[f]);
+  }
   for (int k = 0; k < dr_context::PIPE_STREAMS; k++) ok = ok && event(c->pipe_last[k]);
   ok = ok && event(c->pipe_barrier) && event(c->pipe_sync);
   if (!ok) { set_error("pipeline: cannot create events"); return DR_ERR_DEVICE; }
@@ -408,11 +428,14 @@ void dr_context_destroy(dr_context* c) {
   if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int k = 0; k < 2; k++) { if (c->pev0[k]) (void)hipEventDestroy(c->pev0[k]); if (c->pev1[k]) (void)hipEventDestroy(c->pev1[k]); }
   for (int k = 0; k < dr_context::PIPE_DEPTH; k++) {
-    if (c->pipe_frame[k]) (void)hipFree(c->pipe_frame[k]);
-    if (c->pipe_rgb_dev[k]) (void)hipFree(c->pipe_rgb_dev[k]);
-    if (c->pipe_rgb_host[k]) (void)hipHostFree(c->pipe_rgb_host[k]);
-    if (c->pipe_rendered[k]) (void)hipEventDestroy(c->pipe_rendered[k]);
-    if (c->pipe_added[k]) (void)hipEventDestroy(c->pipe_added[k]);
+    dr_context::PipeSlot& sl = c->pipe_slot[k];
+    if (sl.frames) (void)hipFree(sl.frames);
+    if (sl.rendered) (void)hipEventDestroy(sl.rendered);
+    for (int f = 0; f < dr_context::PIPE_GROUP_MAX; f++) {
+      if (sl.rgb_dev[f]) (void)hipFree(sl.rgb_dev[f]);
+      if (sl.rgb_host[f]) (void)hipHostFree(sl.rgb_host[f]);
+      if (sl.added[f]) (void)hipEventDestroy(sl.added[f]);
+    }
   }
   for (hipEvent_t e : {c->pipe_last[0], c->pipe_last[1], c->pipe_last[2], c->pipe_last[3], c->pipe_barrier, c->pipe_sync}) if (e) (void)hipEventDestroy(e);
   for (int k = 1; k < dr_context::PIPE_STREAMS; k++) if (c->pipe_stream[k]) (void)hipStreamDestroy(c->pipe_stream[k]);
@@ -490,6 +513,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "coop_tiles_per_wave") *value = c->coop_tiles_per_wave;
   else if (n == "pipe_streams") *value = c->pipe_streams;
   else if (n == "pipe_lean") *value = c->pipe_lean;
+  else if (n == "pipe_group") *value = c->pipe_group;
   else if (n == "tree_depth") *value = c->tree_depth;
   else if (n == "wide_tree") *value = c->wide_tree;
   else if (n == "wide_depth") *value = c->wide ? c->wide_depth : 0;          // 0: the scene has no wide structure
@@ -639,57 +663,77 @@ int dr_context_synchronize(dr_context* c) {
   return DR_OK;
 }
 
-int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed, int present_divide_by,
-                       uint64_t* ticket) {
-  if (!c || !settings13) { set_error("null argument"); return DR_ERR_INVALID; }
-  if (!c->accum || c->accW != W || c->accH != H) { set_error("call dr_accum_reset(W, H) first"); return DR_ERR_INVALID; }
-  HIP_TRY(hipSetDevice(c->device));
-  int rc = pipeline_setup(c);
-  if (rc != DR_OK) return rc;
+}  // extern "C"
+
+namespace {
+
+// how many frames a group may hold right now: the option, if the launch configuration has the builds that store every frame of a batch separately
+int pipeline_group_size(const dr_context* c) {
+  if (c->pipe_group <= 1 || c->pipe_lean || !uses_persistent(c) || !persistent_kernel_can_store_per_frame(persistent_cfg(c))) return 1;
+  return c->pipe_group;
+}
+
+// the slot that holds a launched ticket (null: not in flight any more, or still pending)
+dr_context::PipeSlot* pipeline_slot_of(dr_context* c, uint64_t ticket) {
+  for (dr_context::PipeSlot& sl : c->pipe_slot)
+    if (sl.count > 0 && ticket >= sl.first && ticket < sl.first + (uint64_t)sl.count) return &sl;
+  return nullptr;
+}
+
+// launches the frames submitted since the last launch as ONE group
+int pipeline_flush(dr_context* c) {
+  const int n = (int)c->pipe_pending.size();
+  if (n == 0) return DR_OK;
+  const dr_context::PipePending first = c->pipe_pending[0];
+  const uint64_t stride = n > 1 ? c->pipe_pending[1].seed - first.seed : 0;
+  const int W = first.W, H = first.H;
   RenderParams P;
   // (pipe_lean: the lean six-wave build and one queue per XCD, as for long launches -- the tail it leaves runs beside the next frames)
   const int saved_ctpw = c->coop_tiles_per_wave;
   if (c->pipe_lean) c->coop_tiles_per_wave = 0;
-  rc = make_params(c, settings13, W, H, background, frame_seed, P, 1);
+  int rc = make_params(c, first.st, W, H, first.bg, first.seed, P, n);
   c->coop_tiles_per_wave = saved_ctpw;
-  if (rc != DR_OK) return rc;
-  if (c->traversal == DR_TRAVERSAL_ORDERED && c->tree_depth > ORDERED_STACK) { set_error("tree too deep for ordered traversal"); return DR_ERR_SCENE; }
-  const uint64_t k = c->pipe_next;
+  if (rc != DR_OK) { c->pipe_pending.clear(); return rc; }
+  const uint64_t g = c->pipe_groups;
   const int nstreams = c->pipe_streams, depth = nstreams + 1;
-  const int slot = (int)(k % (uint64_t)depth), si = (int)(k % (uint64_t)nstreams);
+  const int si = (int)(g % (uint64_t)nstreams);
+  dr_context::PipeSlot& sl = c->pipe_slot[g % (uint64_t)depth];
   hipStream_t rs = c->pipe_stream[si];
   const size_t elems = (size_t)W * H * 3;
-  if (!c->pipe_dirty) {                       // the first frame after other work: the pipeline's streams start behind it
+  if (!c->pipe_dirty) {                       // the first group after other work: the pipeline's streams start behind it
     HIP_TRY(hipEventRecord(c->pipe_sync, c->stream));
     for (int q = 1; q < dr_context::PIPE_STREAMS; q++) HIP_TRY(hipStreamWaitEvent(c->pipe_stream[q], c->pipe_sync, 0));
     HIP_TRY(hipStreamWaitEvent(c->acc_stream, c->pipe_sync, 0));
     c->pipe_dirty = true;
   }
-  // the slot's previous frame (ticket k - PIPE_DEPTH): its present buffer goes back to the caller first, and its add must have run
-  if (!c->pipe_waited[slot]) { HIP_TRY(hipEventSynchronize(c->pipe_added[slot])); c->pipe_waited[slot] = true; }
-  if (k >= (uint64_t)depth) HIP_TRY(hipStreamWaitEvent(rs, c->pipe_added[slot], 0));
-  if (c->pipe_elems[slot] < elems || !c->pipe_frame[slot]) {
-    if (c->pipe_frame[slot]) { HIP_TRY(hipStreamSynchronize(c->acc_stream)); (void)hipFree(c->pipe_frame[slot]); c->pipe_frame[slot] = nullptr; c->pipe_elems[slot] = 0; }
-    HIP_TRY(hipMalloc((void**)&c->pipe_frame[slot], elems * sizeof(int32_t)));
-    c->pipe_elems[slot] = elems;
-    c->pipe_rect[slot][0] = -1;
+  // the slot's previous group: its present buffers go back to the caller first, and its adds must have run
+  if (!sl.drained && sl.count > 0) { HIP_TRY(hipEventSynchronize(sl.added[sl.count - 1])); sl.drained = true; }
+  if (sl.count > 0) HIP_TRY(hipStreamWaitEvent(rs, sl.added[sl.count - 1], 0));
+  if (sl.elems_each != elems || sl.cap_frames < n || !sl.frames) {
+    if (sl.frames) { HIP_TRY(hipStreamSynchronize(c->acc_stream)); (void)hipFree(sl.frames); sl.frames = nullptr; sl.cap_frames = 0; }
+    const int cap = n > c->pipe_group ? n : c->pipe_group;
+    HIP_TRY(hipMalloc((void**)&sl.frames, (size_t)cap * elems * sizeof(int32_t)));
+    sl.elems_each = elems; sl.cap_frames = cap;
+    sl.rect[0] = -1;
   }
-  // pixels outside the rendered block grid are 0 (K:2633-2636): the buffer is cleared when that grid changes, every frame of a grid
+  // pixels outside the rendered block grid are 0 (K:2633-2636): the buffers are cleared when that grid changes, every frame of a grid
   // overwrites the same pixels
   const int rect[6] = {W, H, P.gx, P.gy, P.stripe_mod, P.stripe_rem};
-  if (memcmp(rect, c->pipe_rect[slot], sizeof(rect)) != 0) {
-    HIP_TRY(hipMemsetAsync(c->pipe_frame[slot], 0, elems * sizeof(int32_t), rs));
-    memcpy(c->pipe_rect[slot], rect, sizeof(rect));
+  if (memcmp(rect, sl.rect, sizeof(rect)) != 0) {
+    HIP_TRY(hipMemsetAsync(sl.frames, 0, (size_t)sl.cap_frames * elems * sizeof(int32_t), rs));
+    memcpy(sl.rect, rect, sizeof(rect));
   }
-  P.out = c->pipe_frame[slot];
+  P.out = sl.frames;
   P.accumulate = 0;
+  P.batch = n; P.batch_seed_stride = stride;
+  P.out_frame_stride = n > 1 ? (uint32_t)elems : 0u;      // (a group of one is an ordinary launch: every build can render it)
   const int tiles = P.ncols * P.gy;
   // the tile order and the costs it is made from are shared by all launches: a launch that refreshes them runs alone (after the other
-  // stream's newest launch, and the launches after it wait for the refresh); all others read the order as it is
+  // streams' newest launches, and the launches after it wait for the refresh); all others read the order as it is
   bool refresh = false;
   if (c->feedback && uses_persistent(c) && tiles > 0) {
     const float geom[5] = {(float)P.W, (float)P.H, (float)(P.stripe_mod * 1024 + P.stripe_rem) + 0.125f * (float)P.regions, (float)P.ncols, (float)P.gy};
-    // (a refresh costs the overlap of two frames, 0.89 against 0.82 ms/frame when every 8th launch refreshes: four times rarer here)
+    // (a refresh costs the overlap of two launches, 0.89 against 0.82 ms/frame when every 8th single-frame launch refreshes: four times rarer here)
     refresh = !c->order_valid || c->order_capacity < tiles || memcmp(c->order_key + 13, geom, sizeof(geom)) != 0 || c->order_age < 2 ||
               c->order_age % (4 * c->feedback_every) == 0;
   }
@@ -709,60 +753,102 @@ int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, 
   }
   HIP_TRY(hipEventRecord(c->pipe_last[si], rs)); c->pipe_last_set[si] = true;
   if (alone) { HIP_TRY(hipEventRecord(c->pipe_barrier, rs)); c->pipe_barrier_set = true; }
-  HIP_TRY(hipEventRecord(c->pipe_rendered[slot], rs));
+  HIP_TRY(hipEventRecord(sl.rendered, rs));
   // fold into the accumulator, in ticket order (K:2213-2218), and make the image of exactly the frames so far (K:2287)
-  HIP_TRY(hipStreamWaitEvent(c->acc_stream, c->pipe_rendered[slot], 0));
-  launch_frame_add(c->acc_stream, c->accum, c->pipe_frame[slot], elems);
-  c->pipe_div[slot] = 0;
-  if (present_divide_by != 0) {
-    const size_t bytes = (size_t)W * H * 3;
-    if (c->pipe_rgb_bytes[slot] < bytes) {
-      HIP_TRY(hipStreamSynchronize(c->acc_stream));
-      if (c->pipe_rgb_dev[slot]) (void)hipFree(c->pipe_rgb_dev[slot]);
-      if (c->pipe_rgb_host[slot]) (void)hipHostFree(c->pipe_rgb_host[slot]);
-      c->pipe_rgb_dev[slot] = nullptr; c->pipe_rgb_host[slot] = nullptr; c->pipe_rgb_bytes[slot] = 0;
-      HIP_TRY(hipMalloc((void**)&c->pipe_rgb_dev[slot], bytes));
-      HIP_TRY(hipHostMalloc((void**)&c->pipe_rgb_host[slot], bytes, hipHostMallocDefault));
-      c->pipe_rgb_bytes[slot] = bytes;
+  HIP_TRY(hipStreamWaitEvent(c->acc_stream, sl.rendered, 0));
+  for (int f = 0; f < n; f++) {
+    launch_frame_add(c->acc_stream, c->accum, sl.frames + (size_t)f * elems, elems);
+    const int div = c->pipe_pending[(size_t)f].div;
+    sl.div[f] = 0; sl.fwaited[f] = false;
+    if (div != 0) {
+      const size_t bytes = (size_t)W * H * 3;
+      if (sl.rgb_bytes[f] < bytes) {
+        HIP_TRY(hipStreamSynchronize(c->acc_stream));
+        if (sl.rgb_dev[f]) (void)hipFree(sl.rgb_dev[f]);
+        if (sl.rgb_host[f]) (void)hipHostFree(sl.rgb_host[f]);
+        sl.rgb_dev[f] = nullptr; sl.rgb_host[f] = nullptr; sl.rgb_bytes[f] = 0;
+        HIP_TRY(hipMalloc((void**)&sl.rgb_dev[f], bytes));
+        HIP_TRY(hipHostMalloc((void**)&sl.rgb_host[f], bytes, hipHostMallocDefault));
+        sl.rgb_bytes[f] = bytes;
+      }
+      launch_present(c->acc_stream, c->accum, sl.rgb_dev[f], W, H, div);
+      HIP_TRY(hipMemcpyAsync(sl.rgb_host[f], sl.rgb_dev[f], bytes, hipMemcpyDeviceToHost, c->acc_stream));
+      sl.div[f] = div;
     }
-    launch_present(c->acc_stream, c->accum, c->pipe_rgb_dev[slot], W, H, present_divide_by);
-    HIP_TRY(hipMemcpyAsync(c->pipe_rgb_host[slot], c->pipe_rgb_dev[slot], bytes, hipMemcpyDeviceToHost, c->acc_stream));
-    c->pipe_div[slot] = present_divide_by;
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(sl.added[f], c->acc_stream));
   }
-  HIP_TRY(hipGetLastError());
-  HIP_TRY(hipEventRecord(c->pipe_added[slot], c->acc_stream));
-  c->pipe_waited[slot] = false;
-  c->pipe_next = k + 1;
+  sl.first = c->pipe_next - (uint64_t)n; sl.count = n; sl.drained = false;
+  c->pipe_groups = g + 1;
   c->stats.launches += tiles > 0 ? 1 : 0;
-  c->stats.frames += 1;
-  c->stats.samples += (uint64_t)(tiles > 0 ? tiles : 0) * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0);
+  c->stats.frames += (uint64_t)n;
+  c->stats.samples += (uint64_t)(tiles > 0 ? tiles : 0) * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0) * (uint64_t)n;
+  c->pipe_pending.clear();
+  return DR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed, int present_divide_by,
+                       uint64_t* ticket) {
+  if (!c || !settings13) { set_error("null argument"); return DR_ERR_INVALID; }
+  if (!c->accum || c->accW != W || c->accH != H) { set_error("call dr_accum_reset(W, H) first"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = pipeline_setup(c);
+  if (rc != DR_OK) return rc;
+  if (c->traversal == DR_TRAVERSAL_ORDERED && c->tree_depth > ORDERED_STACK) { set_error("tree too deep for ordered traversal"); return DR_ERR_SCENE; }
+  {   // a frame that cannot be rendered must fail here, not when its group is launched
+    RenderParams probe;
+    if ((rc = make_params(c, settings13, W, H, background, frame_seed, probe, 1)) != DR_OK) return rc;
+  }
+  // a group holds frames of ONE view whose seeds are in arithmetic progression (what a progressive render submits): anything else starts a new group
+  if (!c->pipe_pending.empty()) {
+    const dr_context::PipePending& p0 = c->pipe_pending[0];
+    const dr_context::PipePending& pl = c->pipe_pending.back();
+    const bool same_view = memcmp(p0.st, settings13, 13 * sizeof(float)) == 0 && p0.W == W && p0.H == H && p0.bg == background;
+    const bool in_step = c->pipe_pending.size() == 1 || frame_seed - pl.seed == c->pipe_pending[1].seed - p0.seed;
+    if (!same_view || !in_step) { if ((rc = pipeline_flush(c)) != DR_OK) return rc; }
+  }
+  dr_context::PipePending p;
+  memcpy(p.st, settings13, sizeof(p.st)); p.W = W; p.H = H; p.bg = background; p.seed = frame_seed; p.div = present_divide_by;
+  c->pipe_pending.push_back(p);
+  const uint64_t k = c->pipe_next;
+  c->pipe_next = k + 1;
   if (ticket) *ticket = k;
+  if ((int)c->pipe_pending.size() >= pipeline_group_size(c)) return pipeline_flush(c);
   return DR_OK;
 }
 
 int dr_pipeline_wait(dr_context* c, uint64_t ticket, uint8_t* out_rgb8) {
   if (!c || !c->pipe_ready) { set_error("pipeline: nothing submitted"); return DR_ERR_INVALID; }
-  const uint64_t depth = (uint64_t)c->pipe_streams + 1;
-  if (ticket >= c->pipe_next || ticket + depth < c->pipe_next) { set_error("pipeline: ticket not in flight (the pipeline keeps pipe_streams + 1 frames)"); return DR_ERR_INVALID; }
   HIP_TRY(hipSetDevice(c->device));
-  const int slot = (int)(ticket % depth);
-  HIP_TRY(hipEventSynchronize(c->pipe_added[slot]));
-  c->pipe_waited[slot] = true;
+  if (ticket < c->pipe_next && ticket + c->pipe_pending.size() >= c->pipe_next) {      // submitted, its group not launched yet: it is now
+    const int rc = pipeline_flush(c);
+    if (rc != DR_OK) return rc;
+  }
+  dr_context::PipeSlot* sl = pipeline_slot_of(c, ticket);
+  if (!sl) { set_error("pipeline: ticket not in flight (the pipeline keeps pipe_streams + 1 groups of frames)"); return DR_ERR_INVALID; }
+  const int f = (int)(ticket - sl->first);
+  HIP_TRY(hipEventSynchronize(sl->added[f]));
+  sl->fwaited[f] = true;
+  if (f == sl->count - 1) sl->drained = true;
   if (out_rgb8) {
-    if (!c->pipe_div[slot]) { set_error("pipeline: that frame was submitted without a present"); return DR_ERR_INVALID; }
-    memcpy(out_rgb8, c->pipe_rgb_host[slot], (size_t)c->accW * c->accH * 3);
+    if (!sl->div[f]) { set_error("pipeline: that frame was submitted without a present"); return DR_ERR_INVALID; }
+    memcpy(out_rgb8, sl->rgb_host[f], (size_t)c->accW * c->accH * 3);
   }
   return DR_OK;
 }
 
 int dr_pipeline_image(dr_context* c, uint64_t ticket, const uint8_t** rgb8) {
   if (!c || !c->pipe_ready || !rgb8) { set_error("pipeline: nothing submitted, or null argument"); return DR_ERR_INVALID; }
-  const uint64_t depth = (uint64_t)c->pipe_streams + 1;
-  if (ticket >= c->pipe_next || ticket + depth < c->pipe_next) { set_error("pipeline: ticket not in flight (the pipeline keeps pipe_streams + 1 frames)"); return DR_ERR_INVALID; }
-  const int slot = (int)(ticket % depth);
-  if (!c->pipe_waited[slot]) { set_error("pipeline: dr_pipeline_wait(ticket) comes first"); return DR_ERR_INVALID; }
-  if (!c->pipe_div[slot]) { set_error("pipeline: that frame was submitted without a present"); return DR_ERR_INVALID; }
-  *rgb8 = c->pipe_rgb_host[slot];
+  dr_context::PipeSlot* sl = pipeline_slot_of(c, ticket);
+  if (!sl) { set_error("pipeline: ticket not in flight (the pipeline keeps pipe_streams + 1 groups of frames)"); return DR_ERR_INVALID; }
+  const int f = (int)(ticket - sl->first);
+  if (!sl->fwaited[f]) { set_error("pipeline: dr_pipeline_wait(ticket) comes first"); return DR_ERR_INVALID; }
+  if (!sl->div[f]) { set_error("pipeline: that frame was submitted without a present"); return DR_ERR_INVALID; }
+  *rgb8 = sl->rgb_host[f];
   return DR_OK;
 }
 
@@ -777,7 +863,7 @@ int dr_render_accumulate_pipelined(dr_context* c, const float settings13[13], in
   if (nframes > 0) {
     const int rc = dr_pipeline_wait(c, last, nullptr);      // adds run in order: the last one ends the batch
     if (rc != DR_OK) return rc;
-    for (int k = 0; k < dr_context::PIPE_DEPTH; k++) c->pipe_waited[k] = true;
+    for (dr_context::PipeSlot& sl : c->pipe_slot) sl.drained = true;
   }
   return DR_OK;
 }

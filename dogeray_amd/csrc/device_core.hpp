@@ -1082,9 +1082,10 @@ __device__ __forceinline__ uint64_t sample_seed(const RenderParams& P, int x, in
   return P.seed + (uint64_t)frame * P.batch_seed_stride + (uint64_t)s * 0x9E3779B97F4A7C15ull +
          (uint64_t)((uint32_t)x + (uint32_t)y * P.seed_stride);
 }
-__device__ __forceinline__ void store_pixel(const RenderParams& P, int x, int y, V3 color) {     // K:1081-1085
+// (frame_offset: launches that render every frame of their batch into a buffer of its own -- the grouped present pipeline -- pass frame * P.out_frame_stride)
+__device__ __forceinline__ void store_pixel(const RenderParams& P, int x, int y, V3 color, size_t frame_offset = 0) {     // K:1081-1085
   int r = f2i(color.x * 255 * P.scale), g = f2i(color.y * 255 * P.scale), b = f2i(color.z * 255 * P.scale);
-  int32_t* px = P.out + ((size_t)x * (size_t)P.H + (size_t)y) * 3;
+  int32_t* px = P.out + frame_offset + ((size_t)x * (size_t)P.H + (size_t)y) * 3;
   if (P.accumulate == 2) {        // frames of one batch may finish the same pixel concurrently; integer adds commute
     atomicAdd(px + 0, r); atomicAdd(px + 1, g); atomicAdd(px + 2, b);
   } else if (P.accumulate) { px[0] += r; px[1] += g; px[2] += b; }

@@ -135,6 +135,7 @@ struct RenderParams {
   int32_t split_parts;            // work-sharing build: parts in which the tiles at the head of the order are handed out (1 = whole)
   int32_t coop_rounds;            // work sharing: hand-over rounds per loop iteration
   int32_t regions;                // persistent kernel: number of tile queues (1, or 8 = one per XCD)
+  uint32_t out_frame_stride;      // int32 words between the output buffers of two frames of a batch (0: one buffer for all: accumulation)
   int32_t region_start[9];        // identity order: region r owns tiles [region_start[r], region_start[r+1])
 };
 

@@ -190,19 +190,25 @@ int main(int argc, char** argv) {
       // one frame per present, as the reference does it -- but pipelined: frame k + 1 is queued before frame k's image is waited for, so
       // its launch starts while frame k's slowest pixels drain; every image is still exactly clamp(sum of the frames so far / count)
       pack13(s, 1, s.spp, s.max_depth, st);
-      uint64_t tickets[2]; int divs[2]; int inflight = 0;
+      // (frames submitted one after the other are rendered in groups -- one launch for up to pipe_group frames, each into its own buffer -- and added and
+      // shown one by one: two groups' worth of frames are kept in flight)
+      int group_opt = 1;
+      (void)dr_context_get_option(ctx, "pipe_group", &group_opt);
+      const size_t window = (size_t)(2 * (group_opt > 1 ? group_opt : 1));
+      std::vector<uint64_t> tickets; std::vector<int> divs;
       auto t_prev = std::chrono::steady_clock::now();
-      while (iter < total_iters || inflight > 0) {
-        if (iter < total_iters && inflight < 2) {
+      while (iter < total_iters || !tickets.empty()) {
+        if (iter < total_iters && tickets.size() < window) {
           iter++;
-          divs[inflight] = iter - 3;                                     // K:2287
-          if (dr_pipeline_submit(ctx, st, W, H, s.background, seed + frame_no * seed_stride, divs[inflight], &tickets[inflight]) != DR_OK) die("submit");
-          frame_no++; inflight++;
-          if (iter < total_iters && inflight < 2) continue;
+          uint64_t t = 0;
+          if (dr_pipeline_submit(ctx, st, W, H, s.background, seed + frame_no * seed_stride, iter - 3, &t) != DR_OK) die("submit");      // K:2287
+          tickets.push_back(t); divs.push_back(iter - 3);
+          frame_no++;
+          if (iter < total_iters && tickets.size() < window) continue;
         }
         if (dr_pipeline_wait(ctx, tickets[0], rgb.data()) != DR_OK) die("present");
         divide_by = divs[0];
-        tickets[0] = tickets[1]; divs[0] = divs[1]; inflight--;
+        tickets.erase(tickets.begin()); divs.erase(divs.begin());
         auto now = std::chrono::steady_clock::now();
         long long us = std::chrono::duration_cast<std::chrono::microseconds>(now - t_prev).count();
         t_prev = now;

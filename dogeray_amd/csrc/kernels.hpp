@@ -33,6 +33,9 @@ int launch_persistent_kernel(hipStream_t stream, const RenderParams& P, const Pe
 
 constexpr int COUNTER_WORDS = 48;   // 64-bit words of a context's statistics buffer: [0, 8) ray counters, [8, 16) dr_stats.diag, [16, 48) the shade / refill phase's budget (dr_stats_phase_counts)
 
+// the launch configuration has builds that store every frame of a batch into its own buffer (RenderParams::out_frame_stride != 0)
+bool persistent_kernel_can_store_per_frame(const PersistentCfg& cfg);
+
 // kernels_aux.hip
 void launch_tile_feedback(hipStream_t stream, const unsigned* pixel_cost, unsigned* tile_cost, int* tile_order, int* region_start, int tiles, int regions,
                           int heavy_factor, int split_steps, int split_limit);

@@ -72,7 +72,9 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
 // code in the loop, so launches whose queue is long enough to hide their tail use the lean build (80 VGPRs and 26 KiB of LDS at
 // OCC = 6: six waves per SIMD; launch_persistent / launch_wide_lean6 pick).
 
-template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE, bool COOP = true>
+// PERFRAME: every frame of the launch's batch is stored into a buffer of its own (P.out + frame * P.out_frame_stride) instead of being added into one: the
+// grouped present pipeline (dr_pipeline_*: the frames of a group share one launch and are added and shown one by one afterwards).
+template <bool COUNT, int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL, bool WIDE, bool COOP = true, bool PERFRAME = false>
 __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParams P, unsigned* __restrict__ tile_counter,
                                                                      const int* __restrict__ tile_order, const int* __restrict__ region_start,
                                                                      unsigned* __restrict__ pixel_cost) {
@@ -270,7 +272,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           // same pixel, next sample (K:1059)
         } else {
           if (px >= 0) {
-            store_pixel(P, px, py, color);
+            store_pixel(P, px, py, color, PERFRAME ? (size_t)frame * (size_t)P.out_frame_stride : (size_t)0);
             if (pixel_cost) pixel_cost[pcode & 0x7fffffff] = steps;
           }
           px = -1;
@@ -650,7 +652,8 @@ bool launch_wide_lean6(hipStream_t stream, const RenderParams& P_in, const Persi
   if ((long long)blocks * 4 > work) blocks = (int)((work + 3) / 4);
   P.wave_log = nullptr;      // (the lean kernel does not log its waves)
   log_waves = 0;
-  hipLaunchKernelGGL((render_persistent_kernel<false, 6, 32, 20, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
+  if (P.out_frame_stride) hipLaunchKernelGGL((render_persistent_kernel<false, 6, 32, 20, 2, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
+  else hipLaunchKernelGGL((render_persistent_kernel<false, 6, 32, 20, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
   return true;
 }
 
@@ -668,10 +671,26 @@ int launch_persistent_occ(hipStream_t stream, const RenderParams& P, const Persi
 
 }  // namespace
 
+bool persistent_kernel_can_store_per_frame(const PersistentCfg& cfg) {
+  return cfg.traversal == DR_TRAVERSAL_WIDE && !cfg.count && cfg.schedule == 0 && cfg.occupancy >= 6;
+}
+
 int launch_persistent_kernel(hipStream_t stream, const RenderParams& P, const PersistentCfg& cfg, unsigned* tile_counter, const int* order,
                              const int* region_start, unsigned* pixel_cost) {
   const int* rstart = order ? region_start : nullptr;        // identity order: the split travels in P.region_start
   int log_waves = 0;
+  if (P.out_frame_stride && !(cfg.occupancy >= 6 && cfg.schedule == 0 && cfg.traversal == DR_TRAVERSAL_WIDE && !cfg.count)) return 0;      // (the caller asked persistent_kernel_can_store_per_frame first)
+  if (P.out_frame_stride) {
+    if (launch_wide_lean6(stream, P, cfg, tile_counter, order, rstart, pixel_cost, log_waves)) return log_waves;
+    // a short group: the work-sharing build, five waves per SIMD
+    const int work = P.ncols * P.gy * P.batch;
+    int blocks = cfg.num_cus * 5;
+    if (blocks * 4 > work) blocks = (work + 3) / 4;
+    RenderParams Q = P;
+    if (Q.wave_log && blocks * 4 > WAVE_LOG_WAVES) Q.wave_log = nullptr;
+    hipLaunchKernelGGL((render_persistent_kernel<false, 5, 32, 20, 2, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, Q, tile_counter, order, rstart, pixel_cost);
+    return Q.wave_log ? blocks * 4 : 0;
+  }
   if (cfg.occupancy >= 6 && launch_wide_lean6(stream, P, cfg, tile_counter, order, rstart, pixel_cost, log_waves)) return log_waves;
   if (cfg.occupancy >= 5) return launch_persistent_occ<5>(stream, P, cfg, tile_counter, order, rstart, pixel_cost);
   return launch_persistent_occ<4>(stream, P, cfg, tile_counter, order, rstart, pixel_cost);

@@ -214,16 +214,23 @@ int dr_context_synchronize(dr_context* c);
 
 /* ---- the present loop at the batched rate: pipelined single frames.
  * The reference renders ONE frame per CudaStarter call, adds it to `outr` and shows the running mean (K:2154-2224, K:2213-2218,
- * K:2287).  A launch of one frame ends with its slowest pixels while most of the GPU idles; here frame k + 1 starts on a second
- * stream while frame k drains.  Every frame renders into a buffer of its own (three rotate) and a third stream adds finished
- * frames to the accumulator IN TICKET ORDER, so what dr_pipeline_wait(ticket) hands out -- clamp(sum of frames <= ticket /
- * present_divide_by, 0, 255), row-major RGB8 as dr_accum_present -- is exactly the image the reference shows after that frame.
+ * K:2287).  A launch of one frame ends with its slowest pixels while most of the GPU idles.  Here frames are SUBMITTED one by one and every
+ * frame still renders into a buffer of its own, but
+ *   - frames submitted one after the other for the same view with seeds in arithmetic progression (what a progressive render submits) share
+ *     one LAUNCH: a group of up to "pipe_group" (option, default 8; 1 = a launch per frame) frames, rendered by the kernel's batch queue into
+ *     that many buffers -- a launch long enough to run the lean build and to hide its tail;
+ *   - group k + 1 starts on a second stream while group k drains ("pipe_streams", default 2; streams + 1 groups of buffers rotate);
+ *   - a third stream adds the finished frames to the accumulator ONE BY ONE IN TICKET ORDER, so what dr_pipeline_wait(ticket) hands out --
+ *     clamp(sum of frames <= ticket / present_divide_by, 0, 255), row-major RGB8 as dr_accum_present -- is exactly the image the reference
+ *     shows after that frame.
  *   dr_pipeline_submit   queues one frame (same arguments as dr_render_frame; the frame must match dr_accum_reset's size);
  *                        present_divide_by != 0 also queues the display divide and its download.  Returns at once; *ticket = 0, 1, 2 ...
- *   dr_pipeline_wait     blocks until that frame has been added (and presented); out_rgb8 may be NULL.  At most three frames are in
- *                        flight: submitting a fourth waits for the oldest.
- *   dr_render_accumulate_pipelined   nframes frames, no presents: dr_render_accumulate's result at one frame per launch.
- * Any other call on the context is ordered behind the frames submitted before it. */
+ *                        The frame's group is launched when it is full, when a frame that does not continue it is submitted, or when it is waited for.
+ *   dr_pipeline_wait     blocks until that frame has been added (and presented); out_rgb8 may be NULL.  A caller that keeps two groups' worth of
+ *                        frames in flight gets the batched rate; one that waits for every frame before it submits the next gets groups of one
+ *                        (the rate of round 3's pipeline).  Tickets of the newest pipe_streams + 1 groups can be waited for.
+ *   dr_render_accumulate_pipelined   nframes frames, no presents: dr_render_accumulate's result through the pipeline.
+ * Any other call on the context is ordered behind the frames submitted before it (their groups are launched first). */
 int dr_pipeline_submit(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed,
                        int present_divide_by, uint64_t* ticket);
 int dr_pipeline_wait(dr_context* c, uint64_t ticket, uint8_t* out_rgb8);

@@ -8,7 +8,7 @@ import numpy as np
 
 OPTION_POOL = {"coop_steps": [1, 2, 8], "coop_rounds": [1, 2, 5], "split_parts": [1, 2, 4, 8], "split_steps": [16, 32, 400], "split_waves": [5, 12, 100, 1000],
                "occupancy": [4, 5, 6], "batch_frames": [1, 2, 3, 32], "feedback_every": [1, 8], "coop_tiles_per_wave": [0, 32, 100000], "schedule": [0, 0, 1, 2],
-               "pipe_streams": [2, 3, 4], "pipe_lean": [0, 1]}
+               "pipe_streams": [2, 3, 4], "pipe_lean": [0, 1], "pipe_group": [1, 2, 3, 8, 16]}
 
 
 def run_campaign(dr, orc, ctx, n_scenes, seed, workdir, texdir, texture_names, sizes=None, log=print):
