@@ -335,10 +335,13 @@ def main():
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(device_index)
+        # a collective that is never matched must end the run, not hang it: torch's watchdog aborts the process after this long (default 10 min)
+        import datetime
+        limit = datetime.timedelta(seconds=int(os.environ.get("DOGERAY_BENCH_TIMEOUT_S", "240")))
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index), timeout=limit)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=limit)
 
     t0 = time.time()
     if rank == 0:
