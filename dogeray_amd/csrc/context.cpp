@@ -680,12 +680,24 @@ dr_context::PipeSlot* pipeline_slot_of(dr_context* c, uint64_t ticket) {
   return nullptr;
 }
 
-// launches the frames submitted since the last launch as ONE group
+int pipeline_flush_some(dr_context* c, int n);
+
+// launches the frames submitted since the last launch: as ONE group if the launch configuration (still) has the builds that store every frame of a batch
+// separately -- an option may have changed since the frames were submitted --, else one by one
 int pipeline_flush(dr_context* c) {
-  const int n = (int)c->pipe_pending.size();
-  if (n == 0) return DR_OK;
+  while (!c->pipe_pending.empty()) {
+    const int all = (int)c->pipe_pending.size();
+    const int rc = pipeline_flush_some(c, pipeline_group_size(c) >= all ? all : 1);
+    if (rc != DR_OK) { c->pipe_pending.clear(); return rc; }
+  }
+  return DR_OK;
+}
+
+// launches the first n pending frames as one group
+int pipeline_flush_some(dr_context* c, int n) {
   const dr_context::PipePending first = c->pipe_pending[0];
   const uint64_t stride = n > 1 ? c->pipe_pending[1].seed - first.seed : 0;
+  const uint64_t first_ticket = c->pipe_next - (uint64_t)c->pipe_pending.size();
   const int W = first.W, H = first.H;
   RenderParams P;
   // (pipe_lean: the lean six-wave build and one queue per XCD, as for long launches -- the tail it leaves runs beside the next frames)
@@ -693,7 +705,7 @@ int pipeline_flush(dr_context* c) {
   if (c->pipe_lean) c->coop_tiles_per_wave = 0;
   int rc = make_params(c, first.st, W, H, first.bg, first.seed, P, n);
   c->coop_tiles_per_wave = saved_ctpw;
-  if (rc != DR_OK) { c->pipe_pending.clear(); return rc; }
+  if (rc != DR_OK) return rc;
   const uint64_t g = c->pipe_groups;
   const int nstreams = c->pipe_streams, depth = nstreams + 1;
   const int si = (int)(g % (uint64_t)nstreams);
@@ -778,12 +790,12 @@ int pipeline_flush(dr_context* c) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(sl.added[f], c->acc_stream));
   }
-  sl.first = c->pipe_next - (uint64_t)n; sl.count = n; sl.drained = false;
+  sl.first = first_ticket; sl.count = n; sl.drained = false;
   c->pipe_groups = g + 1;
   c->stats.launches += tiles > 0 ? 1 : 0;
   c->stats.frames += (uint64_t)n;
   c->stats.samples += (uint64_t)(tiles > 0 ? tiles : 0) * 64ull * (uint64_t)(P.spp_f > 0 ? ceilf(P.spp_f) : 0) * (uint64_t)n;
-  c->pipe_pending.clear();
+  c->pipe_pending.erase(c->pipe_pending.begin(), c->pipe_pending.begin() + n);
   return DR_OK;
 }
 

@@ -679,8 +679,8 @@ int launch_persistent_kernel(hipStream_t stream, const RenderParams& P, const Pe
                              const int* region_start, unsigned* pixel_cost) {
   const int* rstart = order ? region_start : nullptr;        // identity order: the split travels in P.region_start
   int log_waves = 0;
-  if (P.out_frame_stride && !(cfg.occupancy >= 6 && cfg.schedule == 0 && cfg.traversal == DR_TRAVERSAL_WIDE && !cfg.count)) return 0;      // (the caller asked persistent_kernel_can_store_per_frame first)
-  if (P.out_frame_stride) {
+  // (a caller that sets out_frame_stride has asked persistent_kernel_can_store_per_frame for this very configuration: context.cpp pipeline_flush)
+  if (P.out_frame_stride && persistent_kernel_can_store_per_frame(cfg)) {
     if (launch_wide_lean6(stream, P, cfg, tile_counter, order, rstart, pixel_cost, log_waves)) return log_waves;
     // a short group: the work-sharing build, five waves per SIMD
     const int work = P.ncols * P.gy * P.batch;

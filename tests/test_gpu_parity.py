@@ -330,6 +330,20 @@ def test_pipelined_present_loop(dr, orc, ctx, synth, tmp_path):
     ctx.render_accumulate_pipelined(st2, 256, 256, s2.background, 9, 1000003, 13)      # on top of it, then an ordinary call behind the pipeline
     ctx.render_accumulate(st2, 256, 256, s2.background, 9, 1000003, 13)
     assert np.array_equal(ctx.accum_read().astype(np.int64), 3 * want.astype(np.int64))
+    # frames of a group that is still open when an option takes the per-frame-storing builds away are launched one by one; a frame with another seed step or
+    # another view starts a new group; every group size gives the same sums
+    for group in (1, 3, 16):
+        ctx.set_option("pipe_group", group)
+        ctx.accum_reset(256, 256)
+        ts = [ctx.pipeline_submit(st2, 256, 256, s2.background, 9 + k * 1000003) for k in range(5)]
+        ctx.set_option("schedule", 1)
+        ts += [ctx.pipeline_submit(st2, 256, 256, s2.background, 9 + 5 * 1000003), ctx.pipeline_submit(st2, 256, 256, s2.background, 9 + 7 * 1000003 - 1000003)]
+        ctx.pipeline_wait(ts[-1])
+        ctx.set_option("schedule", 0)
+        ts = [ctx.pipeline_submit(st2, 256, 256, s2.background, 9 + k * 1000003) for k in range(7, 13)]
+        ctx.pipeline_wait(ts[-1])
+        assert np.array_equal(ctx.accum_read(), want), group
+    ctx.set_option("pipe_group", 8)
 
 
 def test_moving_camera_keeps_the_previous_views_tile_order(dr, orc, ctx, synth):
