@@ -344,6 +344,17 @@ def test_pipelined_present_loop(dr, orc, ctx, synth, tmp_path):
         ctx.pipeline_wait(ts[-1])
         assert np.array_equal(ctx.accum_read(), want), group
     ctx.set_option("pipe_group", 8)
+    # a camera that moves between submits: every change of view closes the group (K:2341-2500: an interactive viewer); the sum is the sum of the frames
+    st2b = st2.copy(); st2b[0] += 0.25
+    plan = [(st2, 9), (st2, 9 + 1000003), (st2b, 77), (st2b, 77 + 1000003), (st2b, 77 + 2 * 1000003), (st2, 5), (st2b, 6)]
+    ctx.accum_reset(256, 256)
+    for stv, seed in plan:
+        ctx.render_accumulate(stv, 256, 256, s2.background, seed, 0, 1)
+    want_views = ctx.accum_read()
+    ctx.accum_reset(256, 256)
+    ts = [ctx.pipeline_submit(stv, 256, 256, s2.background, seed) for stv, seed in plan]
+    ctx.pipeline_wait(ts[-1])
+    assert np.array_equal(ctx.accum_read(), want_views)
 
 
 def test_moving_camera_keeps_the_previous_views_tile_order(dr, orc, ctx, synth):
