@@ -178,6 +178,9 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *                   help with their rays from the first step
  *                   Threaded walk ("coop_steps" again): once the queue is empty, a ray older than that is finished by all 64
  *                   lanes breadth-first, in waves with at most "coop_lanes" (8) lanes walking
+ *   "pipe_streams"  render streams the present pipeline alternates between (2, default, to 4); "pipe_group": most frames one launch of the pipeline
+ *                   covers (1 to 16, default 8; see dr_pipeline_submit); "pipe_lean" 1: pipelined launches of ONE frame run the lean build on eight queues
+ *                   instead of the work-sharing build (measured slower, default 0; groups are then not formed)
  *   "reserve_cus"   persistent kernel: workgroups are launched for this many CUs fewer than the device has (0 = all; dr_group ranks may leave
  *                   room for the gather's copy / RCCL kernels beside the next batch's rendering)
  *   "wave_log"      1: short launches record begin / queue empty / end of every wave (dr_stats_wave_log)

@@ -328,3 +328,14 @@ def test_rtsb_round_trip(dr, synth, tmp_path):
     with pytest.raises(dr.DogerayError) as e:
         dr.Scene.load_binary(str(tmp_path / "missing.rtsb"))
     assert e.value.code == dr.ERR_IO
+
+
+def test_every_option_is_documented_in_the_header():
+    """Every name dr_context_set_option / dr_context_get_option accepts (csrc/context.cpp) appears, quoted, in include/dogeray_amd.h."""
+    import re
+    src = open(os.path.join(ROOT, "dogeray_amd", "csrc", "context.cpp")).read()
+    hdr = open(os.path.join(ROOT, "include", "dogeray_amd.h")).read()
+    names = set(re.findall(r'name == "(\w+)"', src)) | set(re.findall(r'\bn == "(\w+)"', src))
+    assert len(names) > 20
+    missing = sorted(n for n in names if '"%s"' % n not in hdr)
+    assert not missing, missing
