@@ -124,6 +124,7 @@ _API = [
     ("dr_stats_enable_counters", C.c_int, [_VP, C.c_int]),
     ("dr_stats_reset", C.c_int, [_VP]),
     ("dr_stats_get", C.c_int, [_VP, C.POINTER(DrStats)]),
+    ("dr_context_probe_trace", C.c_int, [_VP, _VP, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("dr_stats_phase_counts", C.c_int, [_VP, C.POINTER(C.c_ulonglong), C.c_int]),
     ("dr_stats_wave_log", C.c_int, [_VP, C.POINTER(C.c_ulonglong), C.c_int, C.POINTER(C.c_int)]),
     ("dr_stats_pixel_cost", C.c_int, [_VP, C.POINTER(C.c_uint), C.c_size_t, C.POINTER(C.c_size_t)]),
@@ -446,6 +447,13 @@ class Context:
         if n.value < out.size:
             return np.zeros((0, 0), dtype=np.uint32)
         return out.reshape(gx, gy, 8, 8).transpose(0, 2, 1, 3).reshape(gx * 8, gy * 8)[:W, :H]
+
+    def probe_trace(self, settings13, W, H, background, frame_seed, frames=2, variant=2):
+        """Trace-only probe (dr_context_probe_trace): (rays per second, rays, results differing from the one-ray-per-lane walk)."""
+        st = _f32(settings13)
+        r = C.c_double(); n = C.c_uint64(); bad = C.c_uint64()
+        _check(lib().dr_context_probe_trace(self._h, _p(st), W, H, float(background), int(frame_seed) & (2 ** 64 - 1), int(frames), int(variant), C.byref(r), C.byref(n), C.byref(bad)))
+        return r.value, int(n.value), int(bad.value)
 
     def probe_gather(self, hot_records=0, iters=2000):
         """Records/s of divergent, dependent 64-byte fetches from the resident wide array (bench.py roofline.gather)."""

@@ -1054,6 +1054,76 @@ int dr_context_probe_gather(dr_context* c, uint32_t hot_records, int iters, doub
   return DR_OK;
 }
 
+int dr_context_probe_trace(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed, int frames, int variant,
+                           double* rays_per_s, uint64_t* n_rays, uint64_t* mismatches) {
+  if (!c || !settings13 || !rays_per_s || !n_rays || !mismatches || frames < 1 || variant < 0) { set_error("bad argument"); return DR_ERR_INVALID; }
+  if (!c->wide || traversal_of(c) != DR_TRAVERSAL_WIDE || !uses_persistent(c)) { set_error("the trace probe needs the wide walk and the persistent kernel"); return DR_ERR_INVALID; }
+  HIP_TRY(hipSetDevice(c->device));
+  int rc = dr_accum_reset(c, W, H);
+  if (rc != DR_OK) return rc;
+  // 1. the rays of ONE frame, as a per-bounce wavefront would hold them: the counting build writes every ray a path starts to slot bounce * pixels + pixel (tile
+  // order); empty slots (paths that had ended) are squeezed out on the host; `frames` copies of the list make the probe's launch long enough to time
+  RenderParams Pv;
+  if ((rc = make_params(c, settings13, W, H, background, frame_seed, Pv, 1)) != DR_OK) return rc;
+  const size_t npix = (size_t)Pv.ncols * Pv.gy * 64;
+  const size_t slots = npix * (size_t)(Pv.max_depth > 0 ? Pv.max_depth : 1);
+  if (slots * (size_t)frames > 0x7fffffffull) { set_error("too many rays"); return DR_ERR_INVALID; }
+  DevBuf<float> raw; DevBuf<float> log; DevBuf<unsigned> cursor; DevBuf<unsigned> out, ref;
+  if ((rc = raw.alloc(slots * 8)) != DR_OK) return rc;
+  HIP_TRY(hipMemset(raw.p, 0, slots * 8 * sizeof(float)));
+  const bool was_counting = c->count;
+  unsigned long long ctl[3] = {0ull, (unsigned long long)(uintptr_t)raw.p, (unsigned long long)slots};      // statistics words 40-42: rays logged, the log, its room
+  HIP_TRY(hipMemcpy(c->counters + 40, ctl, sizeof(ctl), hipMemcpyHostToDevice));
+  c->count = true;
+  rc = dr_render_accumulate(c, settings13, W, H, background, frame_seed, 1000003, 1);
+  c->count = was_counting;
+  const unsigned long long off[2] = {0ull, 0ull};
+  HIP_TRY(hipMemcpy(c->counters + 41, off, sizeof(off), hipMemcpyHostToDevice));
+  if (rc != DR_OK) return rc;
+  std::vector<float> host(slots * 8), packed;
+  if ((rc = raw.get(host.data(), host.size())) != DR_OK) return rc;
+  packed.reserve(host.size() / 2);
+  for (size_t k = 0; k < slots; k++) {
+    const float* r = &host[k * 8];
+    if (r[4] != 0.0f || r[5] != 0.0f || r[6] != 0.0f || r[4] != r[4]) packed.insert(packed.end(), r, r + 8);      // a direction was written
+  }
+  const size_t per_frame = packed.size() / 8;
+  const unsigned n = (unsigned)(per_frame * (size_t)frames);
+  *n_rays = per_frame;
+  if (n == 0) { *rays_per_s = 0; *mismatches = 0; return DR_OK; }
+  if ((rc = log.alloc((size_t)n * 8)) != DR_OK) return rc;
+  for (int f = 0; f < frames; f++) HIP_TRY(hipMemcpy(log.p + (size_t)f * per_frame * 8, packed.data(), per_frame * 8 * sizeof(float), hipMemcpyHostToDevice));
+  std::vector<float>().swap(host);
+  if ((rc = cursor.alloc(1)) != DR_OK || (rc = out.alloc((size_t)n * 2)) != DR_OK || (rc = ref.alloc((size_t)n * 2)) != DR_OK) return rc;
+  RenderParams P;
+  memset(&P, 0, sizeof(P));
+  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax;
+  // 2. the probe, timed (one warm-up, then the best of three)
+  float best = 1e30f;
+  for (int rep = 0; rep < 4; rep++) {
+    HIP_TRY(hipMemsetAsync(cursor.p, 0, sizeof(unsigned), c->stream));
+    HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    launch_trace_probe(c->stream, P, c->num_cus, variant, log.p, n, cursor.p, out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    if (rep > 0 && ms < best) best = ms;
+  }
+  *rays_per_s = (double)n / ((double)best * 1e-3);
+  // 3. every result against the one-ray-per-lane walk
+  launch_trace_probe(c->stream, P, c->num_cus, 0, log.p, n, cursor.p, ref.p);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  std::vector<unsigned> a((size_t)n * 2), b((size_t)n * 2);
+  if ((rc = out.get(a.data(), a.size())) != DR_OK || (rc = ref.get(b.data(), b.size())) != DR_OK) return rc;
+  uint64_t bad = 0;
+  for (size_t i = 0; i < a.size(); i++) bad += a[i] != b[i];
+  *mismatches = bad;
+  return DR_OK;
+}
+
 // ---- KAT hooks
 #define KAT_PRE(n)                                                        \
   if (!c || (n) < 0) { set_error("bad argument"); return DR_ERR_INVALID; } \

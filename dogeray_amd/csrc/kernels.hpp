@@ -44,6 +44,9 @@ void launch_frame_add(hipStream_t stream, int32_t* acc, const int32_t* frame, si
 void launch_stripe_copy(hipStream_t stream, int32_t* dst, const int32_t* src, int ncols, int run4, long long dst_first4, long long dst_stride4,
                         long long src_first4, long long src_stride4);
 void launch_gather_probe(hipStream_t stream, const RenderParams& P, int blocks, unsigned nrec, int iters, unsigned* out);
+// trace-only probe (dr_context_probe_trace): variant 0 = one ray per lane, waves wait for their slowest; 1.. = persistent waves refilling from the ray list
+// (occupancy / lanes that must be free before a refill / lanes at a leaf before a leaf step: 6/1/20, 6/8/20, 6/16/20, 8/8/20, 8/8/28, 6/8/28, 8/4/32)
+void launch_trace_probe(hipStream_t stream, const RenderParams& P, int num_cus, int variant, const float* rays, unsigned n, unsigned* cursor, unsigned* out);
 void launch_kat_rng(hipStream_t stream, uint64_t seed, int n, double* out);
 void launch_kat_aabb(hipStream_t stream, int n, const float* o, const float* d, const float* mn, const float* mx, int32_t* hit, float* dist);
 void launch_kat_node_planes(hipStream_t stream, int n, const uint32_t* w, const float* a, const float* b, float* t_mix, float* t_cvt);

@@ -197,6 +197,79 @@ __global__ __launch_bounds__(256, 5) void gather_probe_kernel(RenderParams P, un
   if (acc == 0x12345678u) out[0] = acc;
 }
 
+// ---- measurement aid: a TRACE-ONLY kernel over a list of rays (dr_context_probe_trace).  What would the walk cost if it were a kernel of its own -- a wave's
+// lanes refilling from a global ray queue in a few instructions, no generator / attenuation / pixel state in its registers, shading done elsewhere?  Same node and
+// leaf steps as the render kernel (exclusive steps, leaf steps once PARK lanes stand at a leaf), results {t bits, slot} per ray ({10000, -1}: no hit).
+template <int OCC, int REFILL_MIN, int PARK>
+__global__ __launch_bounds__(256, OCC) void trace_probe_kernel(RenderParams P, const float4* __restrict__ rays, unsigned n, unsigned* __restrict__ cursor, uint2* __restrict__ out) {
+  __shared__ int lds[4 * WIDE_STACK * 64];
+  const int lane = threadIdx.x & 63;
+  int* const my_stack = lds + (threadIdx.x >> 6) * (WIDE_STACK * 64) + lane;
+  const WalkRsrc walk = wide_rsrc(P);
+  Trav tr; tr.node = -2; tr.best_t = 0; tr.best_slot = -1;      // -2: wants a ray; -1: done, result not written yet; -3: retired
+  WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
+  V3 o = mk(0, 0, 0), d = mk(0, 0, 0), inv = mk(0, 0, 0);
+  WideRay wr = wide_ray_none();
+  SignMask sg = sign_mask(inv);
+  Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned idx = 0;
+  unsigned chunk_next = 0, chunk_end = 0;      // this wave's share of the ray list (wave-uniform)
+  bool exhausted = false;
+  for (;;) {
+    const unsigned long long want = __ballot(tr.node == -1 || tr.node == -2);
+    const unsigned long long walking = __ballot(tr.node >= 0);
+    if (want != 0ull && ((int)__popcll(want) >= REFILL_MIN || walking == 0ull)) {
+      if (tr.node == -1) out[idx] = make_uint2(__float_as_uint(tr.best_t), (unsigned)tr.best_slot);
+      const bool mine = tr.node == -1 || tr.node == -2;
+      if (!exhausted) {
+        const int cnt = (int)__popcll(want);
+        // rays come in chunks of 128 per wave (one atomic on the shared cursor per chunk: a cursor touched at every refill is the bottleneck, 0.35 Grays/s)
+        if (chunk_next + (unsigned)cnt > chunk_end && chunk_next >= chunk_end) {
+          unsigned b = 0;
+          if (lane == 0) b = atomicAdd(cursor, 128u);
+          chunk_next = (unsigned)__builtin_amdgcn_readfirstlane((int)b); chunk_end = chunk_next + 128u;
+        }
+        const unsigned base = chunk_next;
+        const unsigned my = base + (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(want >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)want, 0u));
+        chunk_next = base + (unsigned)cnt < chunk_end ? base + (unsigned)cnt : chunk_end;
+        if (mine) {
+          if (my < n && my < chunk_end) {
+            const float4 a = rays[2 * (size_t)my], b = rays[2 * (size_t)my + 1];
+            idx = my; o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
+            inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            wr = wide_ray(o, inv, P.wide_pmax); sg = sign_mask(inv);
+            trav_begin(tr); ws.top = 0u; ws.sp = 0; ws.sb = 0;
+          } else tr.node = my >= n ? -3 : -2;      // (-2: the chunk ran out in the middle of the wave's request: next refill)
+        }
+        exhausted = chunk_next >= n;
+      } else if (mine) tr.node = -3;
+      if (__ballot(tr.node != -3) == 0ull) break;
+    }
+    for (int u = 0; u < 2; u++) {
+      const bool at_leaf = tr.node >= 0 && (tr.node & 1);
+      const unsigned long long leaves = __ballot(at_leaf), nodes = __ballot(tr.node >= 0 && !(tr.node & 1));
+      const bool do_leaves = leaves != 0ull && ((int)__popcll(leaves) >= PARK || nodes == 0ull || exhausted);
+      const bool do_nodes = !do_leaves || exhausted;
+      if (tr.node >= 0 && (at_leaf ? do_leaves : do_nodes)) {
+        const WideRec r = wide_fetch(walk, tr.node);
+        if (at_leaf) wide_leaf_compute<false>(r, o, d, inv, sg, tr, ws, my_stack, c);
+        else wide_node_compute<false>(r, wr, sg, tr, ws, my_stack, c);
+      }
+    }
+  }
+}
+// the same rays, one per lane, each wave waiting for its slowest (the reference the probe's results are checked against)
+__global__ __launch_bounds__(256) void trace_plain_kernel(RenderParams P, const float4* __restrict__ rays, unsigned n, uint2* __restrict__ out) {
+  __shared__ int lds[4 * WIDE_STACK * 64];
+  const unsigned i = blockIdx.x * 256u + threadIdx.x;
+  if (i >= n) return;
+  int* const stack = lds + (threadIdx.x >> 6) * (WIDE_STACK * 64) + (threadIdx.x & 63);
+  Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
+  const float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
+  const Hit h = closest_hit_wide<false>(wide_rsrc(P), P.wide_pmax, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), c, stack);
+  out[i] = h.slot < 0 ? make_uint2(__float_as_uint(10000.0f), 0xffffffffu) : make_uint2(__float_as_uint(h.t), (unsigned)h.slot);
+}
+
 // ---- known-answer kernels
 __global__ void kat_rng_kernel(uint64_t seed, int n, double* out) {
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -312,6 +385,20 @@ void launch_stripe_copy(hipStream_t stream, int32_t* dst, const int32_t* src, in
 }
 void launch_gather_probe(hipStream_t stream, const RenderParams& P, int blocks, unsigned nrec, int iters, unsigned* out) {
   hipLaunchKernelGGL(gather_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, P, nrec, iters, out);
+}
+void launch_trace_probe(hipStream_t stream, const RenderParams& P, int num_cus, int variant, const float* rays, unsigned n, unsigned* cursor, unsigned* out) {
+  const float4* r4 = reinterpret_cast<const float4*>(rays);
+  uint2* o2 = reinterpret_cast<uint2*>(out);
+  switch (variant) {
+    case 0: hipLaunchKernelGGL(trace_plain_kernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, P, r4, n, o2); break;
+    case 1: hipLaunchKernelGGL((trace_probe_kernel<6, 1, 20>), dim3((unsigned)(num_cus * 6)), dim3(256), 0, stream, P, r4, n, cursor, o2); break;
+    case 2: hipLaunchKernelGGL((trace_probe_kernel<6, 8, 20>), dim3((unsigned)(num_cus * 6)), dim3(256), 0, stream, P, r4, n, cursor, o2); break;
+    case 3: hipLaunchKernelGGL((trace_probe_kernel<6, 16, 20>), dim3((unsigned)(num_cus * 6)), dim3(256), 0, stream, P, r4, n, cursor, o2); break;
+    case 4: hipLaunchKernelGGL((trace_probe_kernel<8, 8, 20>), dim3((unsigned)(num_cus * 8)), dim3(256), 0, stream, P, r4, n, cursor, o2); break;
+    case 5: hipLaunchKernelGGL((trace_probe_kernel<8, 8, 28>), dim3((unsigned)(num_cus * 8)), dim3(256), 0, stream, P, r4, n, cursor, o2); break;
+    case 6: hipLaunchKernelGGL((trace_probe_kernel<6, 8, 28>), dim3((unsigned)(num_cus * 6)), dim3(256), 0, stream, P, r4, n, cursor, o2); break;
+    default: hipLaunchKernelGGL((trace_probe_kernel<8, 4, 32>), dim3((unsigned)(num_cus * 8)), dim3(256), 0, stream, P, r4, n, cursor, o2); break;
+  }
 }
 void launch_kat_rng(hipStream_t stream, uint64_t seed, int n, double* out) { hipLaunchKernelGGL(kat_rng_kernel, dim3(1), dim3(64), 0, stream, seed, n, out); }
 void launch_kat_aabb(hipStream_t stream, int n, const float* o, const float* d, const float* mn, const float* mx, int32_t* hit, float* dist) {

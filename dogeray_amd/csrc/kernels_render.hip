@@ -392,6 +392,15 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           fresh_ray = true;
         }
       }
+      if (COUNT && P.counters[41] != 0ull && fresh_ray && frame == 0) {      // measurement aid (dr_context_probe_trace): the rays the launch's first frame traces, in the
+        // order a per-bounce wavefront would hold them: bounce by bounce, pixels in tile order.  Statistics words 40-42 = rays logged, the log, its room (entries)
+        atomicAdd(&P.counters[40], 1ull);
+        const unsigned long long k = (unsigned long long)bounce * (unsigned long long)(ntiles * 64) + (unsigned long long)(pcode & 0x7fffffff);
+        if (k < P.counters[42]) {
+          float* const r = reinterpret_cast<float*>(P.counters[41]) + k * 8;
+          r[0] = path.rayo.x; r[1] = path.rayo.y; r[2] = path.rayo.z; r[3] = 0.0f; r[4] = path.raydir.x; r[5] = path.raydir.y; r[6] = path.raydir.z; r[7] = 0.0f;
+        }
+      }
       DR_MARK("phase_restore");
       if (WIDE) {
         asm volatile("" ::: "memory");

@@ -326,6 +326,14 @@ int dr_stats_pixel_cost(dr_context* c, unsigned* out, size_t capacity, size_t* n
  * restricts the random walk to the first records of the array (0 = all of it). */
 int dr_context_probe_gather(dr_context* c, uint32_t hot_records, int iters, double* records_per_s);
 
+/* Measurement aid (tools/exp_trace_rate.py): what the walk would cost as a kernel of its own.  Renders ONE frame with the counting build, which writes every ray
+ * it traces into the order a per-bounce wavefront would hold them (bounce by bounce, pixels in tile order); then a TRACE-ONLY kernel walks `frames` copies of that
+ * list -- variant 0: one ray per lane, a wave waits for its slowest; 1..7: persistent waves whose lanes refill from the ray list in a few instructions, 128 rays per
+ * wave and atomic (occupancy / free lanes before a refill / lanes at a leaf before a leaf step: 6/1/20, 6/8/20, 6/16/20, 8/8/20, 8/8/28, 6/8/28, 8/4/32) -- and is
+ * timed (best of three).  *n_rays = rays of the frame; *mismatches = results that differ from the one-ray-per-lane walk (t bits or slot). */
+int dr_context_probe_trace(dr_context* c, const float settings13[13], int W, int H, float background, uint64_t frame_seed, int frames, int variant,
+                           double* rays_per_s, uint64_t* n_rays, uint64_t* mismatches);
+
 /* ------------------------------------------------------------------ known-answer hooks -- */
 /* Run single device functions on caller data (host pointers), for parity tests. */
 int dr_kat_rng(dr_context* c, uint64_t seed, int n, double* out);

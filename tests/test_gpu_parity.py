@@ -401,6 +401,24 @@ def test_wave_log_and_pixel_cost_of_a_single_frame(dr, ctx, synth):
         ctx.set_option("wave_log", 0)
 
 
+def test_trace_only_probe_agrees_with_the_plain_walk(dr, ctx, synth):
+    """dr_context_probe_trace (measurement aid): the rays of one frame, logged by the counting build in wavefront order, walked by the trace-only kernel --
+    persistent waves refilling from the ray list -- give the same (t bits, slot) as the one-ray-per-lane walk, ray for ray; the log holds every ray of the frame."""
+    ps = dr.Scene.load(os.path.join(synth["dir"], "hf_small.rts"))
+    ps.build_bvh()
+    ctx.upload(ps)
+    s = ps.settings()
+    st = dr.pack_settings13(s, 1, spp=1)
+    W, H = 320, 192
+    ctx.enable_counters(True); ctx.stats_reset()
+    ctx.render_frame(st, W, H, s.background, 5)
+    rays = ctx.stats()["rays"]
+    ctx.enable_counters(False)
+    for variant in (0, 1, 3, 7):
+        rate, n, bad = ctx.probe_trace(st, W, H, s.background, 5, frames=2, variant=variant)
+        assert n == rays and bad == 0 and rate > 0, (variant, n, rays, bad)
+
+
 def test_stripes_partition_the_frame(dr, ctx, synth):
     """Multi-GPU partition: block columns bx % R == r; the union over r is the 1-GPU frame."""
     ps = dr.Scene.load(os.path.join(synth["dir"], "hf_small.rts"))
