@@ -156,6 +156,18 @@ int wait_stream(dr_group* g, hipStream_t st, std::chrono::steady_clock::time_poi
   }
 }
 
+// the same for one event (recorded before the call)
+int wait_event(dr_group* g, hipEvent_t ev, std::chrono::steady_clock::time_point t_end, hipError_t* err) {
+  for (;;) {
+    const hipError_t q = hipEventQuery(ev);
+    if (q == hipSuccess) return 0;
+    if (q != hipErrorNotReady) { if (err) *err = q; return 2; }
+    if (g->failed.load()) return 1;
+    if (std::chrono::steady_clock::now() > t_end) return 1;
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
 // one rank's share of dr_group_render_accumulate
 bool rank_work(dr_group* g, int r, const float* st, int W, int H, float bg, uint64_t seed, uint64_t stride, int nframes, int every) {
   G_HIP(hipSetDevice(g->device[(size_t)r]));
@@ -170,7 +182,19 @@ bool rank_work(dr_group* g, int r, const float* st, int W, int H, float bg, uint
     const int slot = batch & 1;
     if (g->failed.load()) return false;
     if (r == g->fail_rank && batch == g->fail_batch) { g->fail("rank " + std::to_string(r) + ": injected failure before batch " + std::to_string(batch)); return false; }
-    if (batch >= 2) G_HIP(hipStreamWaitEvent(render, g->sent[slot][(size_t)r], 0));     // the slot's previous contents have left
+    if (batch >= 2) {
+      // the slot's previous contents must have left before it is packed again -- and the library call below waits on the host for the batch before last
+      // (at most two are in flight): that wait must not be the place where a transfer that is never matched hangs the call, so it is made here, bounded
+      const auto t_slot = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(g->timeout_s));
+      hipError_t err = hipSuccess;
+      const int w = wait_event(g, g->sent[slot][(size_t)r], t_slot, &err);
+      if (w == 2) { g->fail(std::string("rank ") + std::to_string(r) + ": hipEventQuery: " + hipGetErrorString(err)); return false; }
+      if (w == 1) {
+        if (!g->failed.load()) g->fail("rank " + std::to_string(r) + ": the gather of batch " + std::to_string(batch - 2) + " has not ended after " + std::to_string((int)g->timeout_s) + " s (DOGERAY_GROUP_TIMEOUT_S)");
+        return false;
+      }
+      G_HIP(hipStreamWaitEvent(render, g->sent[slot][(size_t)r], 0));
+    }
     G_DR(dr_render_accumulate_async(c, st, W, H, bg, seed + (uint64_t)k * stride, stride, n));
     if (g->n == 1) continue;
     void* pk = nullptr; uint64_t bytes = 0;
