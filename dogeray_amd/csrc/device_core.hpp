@@ -708,7 +708,7 @@ __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, 
     // The candidate is accepted when its primitive is hit AND the leaf's box is entered no farther than the best t (hit() K:484-488: box, then primitive):
     // a conjunction of pure tests, so the order is free.  The primitive first, for every lane (98 % of the lanes pass the box anyway); the box only for the
     // lanes whose primitive is a candidate -- 5 % of them --, and not at all when no lane of the wave has one: 0.5721 against 0.5777 ms/frame
-    // (profiles/r4_e_phase_budget.txt).  The counting build and the host build keep the reference's order: L counts primitives tested behind a passed box.
+    // (profiles/r4_phase_budget.txt).  The counting build and the host build keep the reference's order: L counts primitives tested behind a passed box.
     const int info = (int)r.A.w;
     const float t = prim_hit_kind((info >> WALK_SLOT_BITS) & 3, mk(f(r.B.w), f(r.C.x), f(r.C.y)), mk(f(r.C.z), f(r.C.w), f(r.D.x)), mk(f(r.D.y), f(r.D.z), f(r.D.w)), o, d);
     const int slot = info & ((1 << WALK_SLOT_BITS) - 1);
