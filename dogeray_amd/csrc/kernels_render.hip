@@ -144,6 +144,9 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
 
   // diagnostic stamps (counting build only): wave lifetime, cycles inside the shade/refill phase
   unsigned long long t_begin = 0, t_phase = 0, n_iter = 0, n_phase = 0, n_nodestep = 0, n_leafstep = 0, n_shaded = 0;
+  float* const ray_log = COUNT ? reinterpret_cast<float*>(P.counters[41]) : nullptr;      // measurement aid (dr_context_probe_trace): statistics words 40-42 = rays logged, the log, its room
+  const unsigned long long ray_log_room = COUNT ? P.counters[42] : 0ull;
+  unsigned long long pb_cands = 0, pb_turns = 0, pb_sphere = 0, pb_disk = 0, pb_retired = 0;      // ... the phase's budget (dr_stats_phase_counts)
   unsigned long long r_begin = 0;
   // wave lifetime in shader cycles and in 100 MHz ticks, every build: two clock reads per wave, written to the statistics buffer only
   t_begin = __builtin_readcyclecounter(); r_begin = __builtin_amdgcn_s_memrealtime();
@@ -372,14 +375,9 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           unsigned long long lane_turns = my_turns;
           for (int off = 32; off > 0; off >>= 1) lane_turns += __shfl_xor(lane_turns, off, 64);
           const unsigned n_sphere = (unsigned)__popcll(__ballot(draw_kind == 3)), n_disk = (unsigned)__popcll(__ballot(draw_kind == 2));
-          if (lane == 0) {
-            atomicAdd(&P.counters[16 + (wave_turns < 15u ? wave_turns : 15u)], 1ull);      // histogram of turns per phase
-            atomicAdd(&P.counters[32], lane_turns);                                        // candidates drawn by all lanes
-            atomicAdd(&P.counters[33], (unsigned long long)wave_turns);                    // turns the waves ran
-            atomicAdd(&P.counters[34], (unsigned long long)n_sphere);                      // lanes that drew a point in the sphere (scatter)
-            atomicAdd(&P.counters[35], (unsigned long long)n_disk);                        // lanes that drew a point in the disk (new path)
-            atomicAdd(&P.counters[36], (unsigned long long)__popcll(__ballot(tr.node == -3)));   // retired lanes at the phase
-          }
+          const unsigned n_retired = (unsigned)__popcll(__ballot(tr.node == -3));
+          if (lane == 0) atomicAdd(&P.counters[16 + (wave_turns < 15u ? wave_turns : 15u)], 1ull);      // histogram of turns per phase (the sums below leave with the wave)
+          pb_cands += lane_turns; pb_turns += wave_turns; pb_sphere += n_sphere; pb_disk += n_disk; pb_retired += n_retired;
         }
         if (scatter_me) shade_scatter(path, sc, pt, rng);
         if (new_path) {
@@ -392,12 +390,12 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           fresh_ray = true;
         }
       }
-      if (COUNT && P.counters[41] != 0ull && fresh_ray && frame == 0) {      // measurement aid (dr_context_probe_trace): the rays the launch's first frame traces, in the
+      if (COUNT && ray_log && fresh_ray && frame == 0) {      // measurement aid (dr_context_probe_trace): the rays the launch's first frame traces, in the
         // order a per-bounce wavefront would hold them: bounce by bounce, pixels in tile order.  Statistics words 40-42 = rays logged, the log, its room (entries)
         atomicAdd(&P.counters[40], 1ull);
         const unsigned long long k = (unsigned long long)bounce * (unsigned long long)(ntiles * 64) + (unsigned long long)(pcode & 0x7fffffff);
-        if (k < P.counters[42]) {
-          float* const r = reinterpret_cast<float*>(P.counters[41]) + k * 8;
+        if (k < ray_log_room) {
+          float* const r = ray_log + k * 8;
           r[0] = path.rayo.x; r[1] = path.rayo.y; r[2] = path.rayo.z; r[3] = 0.0f; r[4] = path.raydir.x; r[5] = path.raydir.y; r[6] = path.raydir.z; r[7] = 0.0f;
         }
       }
@@ -591,6 +589,11 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
     atomicAdd(&P.counters[12], n_nodestep);
     atomicAdd(&P.counters[13], n_leafstep);
     atomicAdd(&P.counters[14], n_shaded);
+    atomicAdd(&P.counters[32], pb_cands);        // candidates drawn by all lanes
+    atomicAdd(&P.counters[33], pb_turns);        // turns the waves ran
+    atomicAdd(&P.counters[34], pb_sphere);       // lanes that drew a point in the sphere (scatter)
+    atomicAdd(&P.counters[35], pb_disk);         // lanes that drew a point in the disk (new path)
+    atomicAdd(&P.counters[36], pb_retired);      // retired lanes summed over phases
   }
   if (COUNT) {
     unsigned v[8] = {c.rays, c.V, c.L, c.S, c.T, c.samples, c.trav_slots, c.ray_slots};

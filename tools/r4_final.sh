@@ -11,5 +11,5 @@ mkdir -p gpurun_out/prof_r4z && rm -rf gpurun_out/prof_r4z/trace && mv gpurun_ou
 for c in C2 C3 C5; do
   timeout -k 10 400 python3 bench.py --config $c --steps 16 --warmup 4 --repeats 5 --no-traffic --no-cpu-baseline > gpurun_out/r4z_bench_$c.json 2> gpurun_out/r4z_bench_$c.err; echo "$c rc=$?"
 done
-timeout -k 10 900 python3 tools/fuzz_campaign.py ${FUZZ_SCENES:-1500} 40004 > gpurun_out/r4z_fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -2 gpurun_out/r4z_fuzz.txt
-FUZZ_SIZES=8,9,16,24,33,40 timeout -k 10 400 python3 tools/fuzz_campaign.py ${FUZZ_TINY:-300} 40005 > gpurun_out/r4z_fuzz_tiny.txt 2>&1; echo "fuzz tiny rc=$?"; tail -1 gpurun_out/r4z_fuzz_tiny.txt
+timeout -k 10 900 python3 tools/fuzz_campaign.py ${FUZZ_SCENES:-800} 40004 > gpurun_out/r4z_fuzz.txt 2>&1; echo "fuzz rc=$?"; tail -2 gpurun_out/r4z_fuzz.txt
+FUZZ_SIZES=8,9,16,24,33,40 timeout -k 10 400 python3 tools/fuzz_campaign.py ${FUZZ_TINY:-200} 40005 > gpurun_out/r4z_fuzz_tiny.txt 2>&1; echo "fuzz tiny rc=$?"; tail -1 gpurun_out/r4z_fuzz_tiny.txt
