@@ -83,7 +83,14 @@ struct Xorwow {
   __device__ __forceinline__ uint32_t next() {
     uint32_t t = v0 ^ (v0 >> 2);
     v0 = v1; v1 = v2; v2 = v3; v3 = v4;
-    v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1));      // (the compiler already folds three of the four terms into one v_bitop3_b32; spelling t << 1 as t + t changes nothing, it turns it back into a shift)
+#ifndef DR_HOST_BUILD
+    // t << 1 as t + t and the three-way xor as ONE v_bitop3_b32: both at the fast class's 2.4 cycles; spelled in plain C++ the compiler turns t + t back
+    // into a 4.2-cycle shift and emits three v_xor (7 instead of 8 instructions per output, -0.4 % of the frame: profiles/r4_m_rejection_loop.txt)
+    uint32_t t2; asm("v_add_u32 %0, %1, %1" : "=v"(t2) : "v"(t));
+    v4 = __builtin_amdgcn_bitop3_b32(t, t2, v4 << 4, 0x96) ^ v4;
+#else
+    v4 = (v4 ^ (v4 << 4)) ^ (t ^ (t << 1));
+#endif
     d += 362437u;
     return v4 + d;
   }
@@ -151,25 +158,66 @@ __device__ __forceinline__ V3 rand_in_unit_disk(Xorwow& r) {     // K:988-994
 // draws is exactly that of rand_in_unit_sphere / rand_in_unit_disk, but the wave runs the loop once, for as many turns as its unluckiest lane needs,
 // instead of once per kind (the persistent kernel's shade / refill phase: the lanes that scatter and the lanes that start a path).
 // (turns: counting builds only -- the number of candidates this lane drew; the wave runs the loop for as many turns as its unluckiest lane)
+// A turn of that loop does not convert its candidate exactly.  It classifies it from the top 32 bits of each 53-bit draw -- T = y ^ (x >> 21) are the
+// top 32 bits of z = x ^ (y << 21) | (y >> 11) << 32 -- as c~ = RN32(RN32((float)T) * 2^-31 - 1), and rejects it only when the approximate squared length
+// says "certainly outside"; whatever is not rejected is converted exactly AFTER the loop and put to the reference's own test (outside_unit), and a lane
+// whose candidate fails that test goes back into the loop.  So the sequence of draws and the accepted point are the reference's as long as
+//     d2~ >= 1 + 2^-16   implies   outside_unit(d2) for the exactly converted candidate:
+//  * with v = 2 (z + 0.5) 2^-53 - 1 the real number both conversions approximate: exact conversion |c - v| <= 3 * 2^-25 (sphere lanes: RN64 then RN32 of
+//    fma(Z, 2^-52, -1) <= 2^-25 + 2^-52; disk lanes: RN32(u) * 2 - 1 with one more rounding <= 2^-25 when the result is below -0.5); the approximation
+//    |c~ - v| <= 2^-24 ((float)T, half an ulp of 2^32, times 2^-31) + 2^-25 (the fma's rounding) + 2^-31 (the 21 bits dropped) -- so |c~ - c| < 2^-22;
+//  * three coordinates of magnitude <= 1: the real sums of squares differ by less than 3 * 2 * 2^-22 < 2^-19; either float evaluation (three products <= 1,
+//    two sums < 4) is within 5 * 2^-23 of its real sum; so |d2~ - d2| < 2^-19 + 2 * 5 * 2^-23 < 2^-17;
+//  * hence d2~ >= 1 + 2^-16 gives d2 > 1 + 2^-17 > 1 + 2^-20, where outside_unit() is true (its own argument above).
+// The accepted candidate's words are not kept through the loop: XORWOW's state IS its last five outputs (v0..v4 = w[n-4..n], output k = w[k] + d[k], d[k] =
+// d - (n - k) * 362437), so the last four draws of a disk lane are rebuilt from the state and a sphere lane keeps one word, the first of its six.
+// (tools/host_kernel.cpp hk_check_reject compares the loop with rand_in_unit_sphere / rand_in_unit_disk, draw for draw.)
+__device__ __forceinline__ float reject_coord(uint32_t x, uint32_t y) {
+  return __builtin_fmaf((float)(y ^ (x >> 21)), 0x1p-31f, -1.0f);
+}
+__device__ __forceinline__ double z_plus_half_of(uint32_t x, uint32_t y) {      // Xorwow::z_plus_half() of the two outputs x, y
+  const uint32_t lo = x ^ (y << 21), hi = y >> 11;
+  const double d_hi = bits_double(0x45300000u, hi), d_lo = bits_double(0x43300000u, lo);
+  return ((d_hi - 19342813118337666422669312.0) + d_lo) + 0.5;
+}
 template <bool COUNT = false>
 __device__ __forceinline__ V3 rand_points_merged(Xorwow& r, int kind, unsigned* turns = nullptr) {
   V3 p = mk(0, 0, 0);
   bool todo = kind != 0;
-  while (todo) {
-    DR_MARK("reject_turn");
-    if (COUNT) (*turns)++;
-    const double zx = r.z_plus_half(), zy = r.z_plus_half();
+  uint32_t first = 0;
+  for (;;) {
+    while (todo) {
+      DR_MARK("reject_turn");
+      if (COUNT) (*turns)++;
+      const uint32_t a = r.next(), b = r.next(), c = r.next(), e = r.next();
+      first = a;
+      const float x = reject_coord(a, b), y = reject_coord(c, e);
+      float d2 = __builtin_fmaf(y, y, x * x);
+      if (kind == 3) {
+        const uint32_t f = r.next(), g = r.next();
+        const float z = reject_coord(f, g);
+        d2 = __builtin_fmaf(z, z, d2);
+      }
+      todo = d2 >= 1.0f + 0x1p-16f;
+    }
+    DR_MARK("reject_done");
+    if (kind == 0) break;
+    // the candidate's words, out of the generator's state
+    const uint32_t d0 = r.d, d1 = d0 - 362437u, d2w = d1 - 362437u, d3 = d2w - 362437u, d4 = d3 - 362437u;
+    const uint32_t o0 = r.v4 + d0, o1 = r.v3 + d1, o2 = r.v2 + d2w, o3 = r.v1 + d3, o4 = r.v0 + d4;
+    const bool sphere = kind == 3;
+    const double zx = z_plus_half_of(sphere ? first : o3, sphere ? o4 : o2), zy = z_plus_half_of(sphere ? o3 : o1, sphere ? o2 : o0);
     float x, y, z = 0.0f;
-    if (kind == 3) {
+    if (sphere) {
       x = (float)__builtin_fma(zx, 0x1p-52, -1.0); y = (float)__builtin_fma(zy, 0x1p-52, -1.0);
-      z = r.uniform_pm1();
+      z = (float)__builtin_fma(z_plus_half_of(o1, o0), 0x1p-52, -1.0);
     } else {
       x = (float)(zx * 0x1p-53) * 2 - 1; y = (float)(zy * 0x1p-53) * 2 - 1;      // randy() * 2 - 1
     }
     p = mk(x, y, z);
     todo = outside_unit(dot(p, p));
+    if (!todo) break;
   }
-  DR_MARK("reject_done");
   return p;
 }
 
@@ -880,8 +928,16 @@ __device__ __forceinline__ uint32_t tex_fetch(const DevTex* __restrict__ tex, co
   if (j < 0) j = 0;
   return texels[(size_t)t.offset + (size_t)j * (size_t)t.w + (size_t)i];
 }
+// b / 255 for a texel byte b, as the IEEE division rounds it, in three fast instructions instead of the division's eleven: with c = RN(1 / 255),
+// q0 = RN(b c), the residual b - 255 q0 is exact in an fma and q = RN(q0 + residual * c) is the correctly rounded quotient (all 256 bytes are compared
+// with the division in tools/host_kernel.cpp hk_check_uniform).
+__device__ __forceinline__ float byte_over_255(uint32_t b) {
+  const float x = float(b), c = 0x1.010102p-8f;
+  const float q0 = x * c;
+  return __builtin_fmaf(__builtin_fmaf(-255.0f, q0, x), c, q0);
+}
 __device__ __forceinline__ V3 rgb_of(uint32_t px) {
-  return mk(float(px & 255u) / 255, float((px >> 8) & 255u) / 255, float((px >> 16) & 255u) / 255);
+  return mk(byte_over_255(px & 255u), byte_over_255((px >> 8) & 255u), byte_over_255((px >> 16) & 255u));
 }
 
 // getnormal K:703-773 on the device records of one primitive (prims: pA..pC, shade: s0..s4, s6): the unflipped normal and the
@@ -965,7 +1021,7 @@ __device__ __forceinline__ bool shade_prepare(const RenderParams& P, const Path&
   }
   if (rtexnum >= 0) {
     uint32_t px = tex_fetch<COUNT>(P.tex, P.texels, rtexnum, texco.x, -texco.y + 1, c);
-    rough = float(px & 255u) / 255 / 2;
+    rough = byte_over_255(px & 255u) / 2;
   }
   if (!(mat == 0 || mat == 2 || mat == 3 || mat == 4 || mat == 5)) { emitted = ocolor * path.atten; return false; }      // emissive (and every unknown material) K:941-944
   // ---- the random draws come first (K:848-944), ONE copy of each loop for every lane that needs it: diffuse (0), metal (3) and glossy (5) all draw

@@ -80,6 +80,16 @@ def test_restated_uniform_draws_round_like_the_plain_expressions(hk):
     assert hk.lib().hk_check_uniform(20_000_000, 12345) == 0
 
 
+def test_merged_rejection_loop_draws_the_reference_points(hk):
+    """rand_points_merged rejects candidates from a 32-bit approximation and converts only the accepted one exactly (out of the generator's state):
+    on 3 million generator states it must return rand_in_unit_sphere's / rand_in_unit_disk's point bit for bit and leave the generator in the
+    same state; the largest gap between the approximate and the exact squared length stays far inside the 2^-17 the proof allows"""
+    import ctypes as C
+    gap = C.c_double(0)
+    assert hk.lib().hk_check_reject(3_000_000, 777, C.byref(gap)) == 0
+    assert 0 < gap.value < 2.0 ** -19
+
+
 def test_host_build_stripes_and_thread_counts_do_not_change_pixels(hk, orc, synth):
     path = os.path.join(synth["dir"], "city_small.rts")
     a = orc.Scene(path)

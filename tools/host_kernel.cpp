@@ -77,6 +77,8 @@ long long hk_check_uniform(long long n, unsigned long long seed) {
   for (long long i = 0; i < n; i++) { const uint64_t r = rnd(); one((uint32_t)r, (uint32_t)(r >> 32)); }
   const uint32_t corners[] = {0u, 1u, 2u, 3u, 0x7ffu, 0x800u, 0x801u, 0x3ffu, 0x400u, 0x401u, 0x7fffffffu, 0x80000000u, 0x80000001u, 0xfffffffeu, 0xffffffffu, 0x001fffffu, 0x00200000u, 0xffe00000u, 0xffdfffffu};
   for (uint32_t a : corners) for (uint32_t b : corners) one(a, b);
+  // a texel byte over 255 (byte_over_255) against the division
+  for (uint32_t b8 = 0; b8 < 256; b8++) { const volatile float num = (float)b8, den = 255.0f; const float plain = num / den, fast = byte_over_255(b8); if (memcmp(&plain, &fast, 4) != 0) bad++; }
   // the rejection test: floats around 1 (every float within 2^-18 of 1) and a sweep
   auto test = [&bad](float d2) {
     const volatile float l = sqrtf(d2);
@@ -85,6 +87,38 @@ long long hk_check_uniform(long long n, unsigned long long seed) {
   };
   for (int k = -(1 << 18); k <= (1 << 18); k++) { uint32_t b = 0x3f800000u + (uint32_t)k; float f; memcpy(&f, &b, 4); test(f); }
   for (long long i = 0; i < n / 4; i++) { const uint64_t r = rnd(); test((float)(r >> 40) * (3.0f / 16777216.0f)); }
+  return bad;
+}
+
+// The merged rejection loop (device_core.hpp rand_points_merged: candidates classified from 32 bits, the accepted one converted exactly from the
+// generator's state) against rand_in_unit_sphere / rand_in_unit_disk on n generator states: the same point, bit for bit, and the same state afterwards.
+// Returns mismatches; *max_d2_gap (optional) = the largest |d2~ - d2| seen over all candidates, to set beside the bound of the proof (2^-17).
+long long hk_check_reject(long long n, unsigned long long seed, double* max_d2_gap) {
+  long long bad = 0;
+  double gap = 0;
+  uint64_t s = seed * 0x9E3779B97F4A7C15ull + 1;
+  auto rnd = [&s]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+  for (long long i = 0; i < n; i++) {
+    Xorwow a; a.init(rnd());
+    const int warm = (int)(rnd() % 7); for (int k = 0; k < warm; k++) a.next();
+    for (int kind = 2; kind <= 3; kind++) {
+      Xorwow plain = a, merged = a;
+      const V3 want = kind == 3 ? rand_in_unit_sphere(plain) : rand_in_unit_disk(plain);
+      const V3 got = rand_points_merged<false>(merged, kind);
+      if (memcmp(&want, &got, sizeof(V3)) != 0 || memcmp(&plain, &merged, sizeof(Xorwow)) != 0) bad++;
+    }
+    // the gap between the approximate and the exact squared length of one candidate of each kind
+    Xorwow g = a;
+    const uint32_t o[6] = {g.next(), g.next(), g.next(), g.next(), g.next(), g.next()};
+    const float xs = (float)__builtin_fma(z_plus_half_of(o[0], o[1]), 0x1p-52, -1.0), ys = (float)__builtin_fma(z_plus_half_of(o[2], o[3]), 0x1p-52, -1.0), zs = (float)__builtin_fma(z_plus_half_of(o[4], o[5]), 0x1p-52, -1.0);
+    const float xd = (float)(z_plus_half_of(o[0], o[1]) * 0x1p-53) * 2 - 1, yd = (float)(z_plus_half_of(o[2], o[3]) * 0x1p-53) * 2 - 1;
+    const float xa = reject_coord(o[0], o[1]), ya = reject_coord(o[2], o[3]), za = reject_coord(o[4], o[5]);
+    const double g3 = fabs((double)dot(mk(xs, ys, zs), mk(xs, ys, zs)) - (double)__builtin_fmaf(za, za, __builtin_fmaf(ya, ya, xa * xa)));
+    const double g2 = fabs((double)dot(mk(xd, yd, 0), mk(xd, yd, 0)) - (double)__builtin_fmaf(ya, ya, xa * xa));
+    if (g3 > gap) gap = g3;
+    if (g2 > gap) gap = g2;
+  }
+  if (max_d2_gap) *max_d2_gap = gap;
   return bad;
 }
 
