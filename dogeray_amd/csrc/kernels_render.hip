@@ -665,11 +665,7 @@ bool launch_wide_lean6(hipStream_t stream, const RenderParams& P_in, const Persi
   P.wave_log = nullptr;      // (the lean kernel does not log its waves)
   log_waves = 0;
   if (P.out_frame_stride) hipLaunchKernelGGL((render_persistent_kernel<false, 6, 32, 20, 2, true, false, true>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
-#ifndef DR_X_TRAV
-#define DR_X_TRAV 32
-#define DR_X_PARK 20
-#endif
-  else hipLaunchKernelGGL((render_persistent_kernel<false, 6, DR_X_TRAV, DR_X_PARK, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
+  else hipLaunchKernelGGL((render_persistent_kernel<false, 6, 32, 20, 2, true, false>), dim3((unsigned)blocks), dim3(256), 0, stream, P, counter, order, rstart, pixel_cost);
   return true;
 }
 
