@@ -646,15 +646,15 @@ __device__ __forceinline__ unsigned bit_and_or(unsigned a, unsigned b, unsigned 
 __device__ __forceinline__ unsigned bit_andn(unsigned a, unsigned b, unsigned c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x08); }
 #endif
 template <class Sign>
-__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, const WideRay& wr, const Sign& sg, float best_t, unsigned& near_key) {
+__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, const WideRay& wr, const Sign& sg, float best_t, unsigned& near_key) {
   const float ox = __uint_as_float(A.x), oy = __uint_as_float(A.y), oz = __uint_as_float(A.z);
-  const float sx24 = __uint_as_float(B.x), sy24 = __uint_as_float(B.y), sz24 = __uint_as_float(B.z);      // scale * 2^24
+  const float sx24 = __uint_as_float(C.z << 16), sy24 = __uint_as_float(C.z & 0xffff0000u), sz24 = __uint_as_float(C.w);      // scale * 2^24 (x, y: upper halves of their floats)
   const V3 inv = wr.inv;
   // the plane entered first is `hi` for a negative direction (slab(): same rule, so the comparison stays plane by plane)
   // (sg holds the signs of the plain 1/direction; the clamped one differs for a NaN only, and a NaN axis has NaN planes whichever word is read)
-  const unsigned nxw = sg.sel(0, C.x, C.w), fxw = sg.sel(0, C.w, C.x);
-  const unsigned nyw = sg.sel(1, C.y, D.x), fyw = sg.sel(1, D.x, C.y);
-  const unsigned nzw = sg.sel(2, C.z, D.y), fzw = sg.sel(2, D.y, C.z);
+  const unsigned nxw = sg.sel(0, B.x, B.w), fxw = sg.sel(0, B.w, B.x);
+  const unsigned nyw = sg.sel(1, B.y, C.x), fyw = sg.sel(1, C.x, B.y);
+  const unsigned nzw = sg.sel(2, B.z, C.y), fzw = sg.sel(2, C.y, B.z);
   unsigned fail[4], kk[4];
   const float tcap = best_t;
   const float ax = sx24 * inv.x, ay = sy24 * inv.y, az = sz24 * inv.z;
@@ -681,12 +681,12 @@ __device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u3
   near_key = k01 < k23 ? k01 : k23;
   // bit k of z = child k failed (the bits above are child 3's): three bitwise selects, then ~z & valid mask in one more
   const unsigned z = bit_select(bit_select(fail[3], fail[2], 4u), bit_select(fail[1], fail[0], 1u), 3u);      // bits 0-1 from the second, the rest from the first
-  return bit_andn(z, B.w, 15u);
+  return bit_andn(z, A.w >> 24, 15u);
 }
 
-__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, u32x4 D, V3 inv_plain, const WideRay& wr, float best_t, unsigned& near_key) {
+__device__ __forceinline__ unsigned wide_node_test(u32x4 A, u32x4 B, u32x4 C, V3 inv_plain, const WideRay& wr, float best_t, unsigned& near_key) {
   SignCmp sg; sg.inv = inv_plain;      // the planes chosen by comparing, as the reference does (per-tile kernel, host studies)
-  return wide_node_test(A, B, C, D, wr, sg, best_t, near_key);
+  return wide_node_test(A, B, C, wr, sg, best_t, near_key);
 }
 
 // (t, slot) as one 64-bit key whose unsigned order is the lexicographic order of the pair (t is positive, or the 10000 of
@@ -706,16 +706,20 @@ __device__ __forceinline__ void wide_pop(Trav& tr, WideStack& ws, const int* __r
   ws.top = (ws.top & 15u) ? ws.top : 0u;
 }
 
-// One record = four 16-byte units, fetched together whatever the record is (a lane learns from the parent's leaf
-// mask, not from the record, whether it is a leaf).  The empty asm pins all four loads in front of the first
-// use: without it hipcc sinks the leaf's primitive units behind the box test, a second dependent round trip.
+// One record = four 16-byte units; a node is its first three (device_layout.h), a leaf all four: the fourth is fetched by the lanes at a leaf only (a
+// lane knows from the parent's leaf mask which it is) -- every load instruction of a step costs about 1 % of the frame (profiles/r4_o_node_three_units.txt).
+// The empty asm pins the loads in front of the first use: without it hipcc sinks the leaf's primitive units behind the box test, a second dependent round trip.
 struct WideRec { u32x4 A, B, C, D; };
 __device__ __forceinline__ WideRec wide_fetch(WalkRsrc wide, int node) {
   const unsigned off = (unsigned)(node >> 1) << 6;
   WideRec r;
-  r.A = ld_unit_raw(wide, off); r.B = ld_unit_raw(wide, off + 16); r.C = ld_unit_raw(wide, off + 32); r.D = ld_unit_raw(wide, off + 48);
+  r.A = ld_unit_raw(wide, off); r.B = ld_unit_raw(wide, off + 16); r.C = ld_unit_raw(wide, off + 32);
 #ifndef DR_HOST_BUILD
+  asm volatile("" : "=v"(r.D));      // (a node lane's fourth unit is never read: no value, no instruction)
+  if (node & 1) r.D = ld_unit_raw(wide, off + 48);
   asm volatile("" : "+v"(r.A), "+v"(r.B), "+v"(r.C), "+v"(r.D));
+#else
+  r.D = ld_unit_raw(wide, off + 48);
 #endif
   return r;
 }
@@ -725,13 +729,13 @@ __device__ __forceinline__ void wide_node_compute(const WideRec& r, const WideRa
   DR_MARK("node_begin");
   if (COUNT) c.V++;
   unsigned key;
-  const unsigned mask = wide_node_test(r.A, r.B, r.C, r.D, wr, sg, tr.best_t, key);
+  const unsigned mask = wide_node_test(r.A, r.B, r.C, wr, sg, tr.best_t, key);
   if (mask != 0u) {
     // nearest entered child next; the others wait as one stack word.  An unused child slot (inverted box, valid bit
     // clear) can only pass on a degenerate grid or ray; if it even has the smallest key, take the lowest valid one.
     int near = (int)(key & 3u);
     near = ((mask >> near) & 1u) ? near : __builtin_ctz(mask);
-    const unsigned base = r.A.w & 0xffffffu, leafmask = (r.B.w >> 4) & 15u;
+    const unsigned base = r.A.w & 0xffffffu, leafmask = r.A.w >> 28;
     const unsigned rest = mask & ~(1u << near);
     if (rest != 0u) {
       if (ws.top != 0u) { if (ws.sp < WIDE_STACK) { stack[ws.sp * 64] = (int)ws.top; ws.sp++; } }   // the host bounds the depth; the guard only protects LDS

@@ -35,13 +35,21 @@ constexpr int WALK_SLOT_BITS = 26;                    // slots < 2^26 (the walk 
 constexpr int WALK_KIND_SPHERE = 0, WALK_KIND_TRIANGLE = 1, WALK_KIND_NONE = 2;   // object type 0 / 2 / anything else
 
 // Wide walk (wide_builder.cpp): 64-byte records, a 4-way tree over the same leaves.
-//   node  {origin.xyz, 0x80000000 | index of first child} {scale.xyz * 2^24, valid mask | leaf mask << 4}
-//         {lo.x, lo.y, lo.z, hi.x} {hi.y, hi.z, -, -}   each lo/hi word = one byte per child: plane = fmaf(byte, scale, origin);
-//         scale is a power of two in [2^-60, 2^36] and is stored times 2^24: the kernel reads a plane byte as the f16 denormal
-//         byte * 2^-24 (device_core.hpp wide_node_test)
+//   node  {origin.xyz, index of first child | valid mask << 24 | leaf mask << 28} {lo.x, lo.y, lo.z, hi.x} {hi.y, hi.z, scale.x | scale.y << 16, scale.z} {-}
+//         each lo/hi word = one byte per child: plane = fmaf(byte, scale, origin); scale is a power of two in [2^-60, 2^36] and is stored times 2^24
+//         (the kernel reads a plane byte as the f16 denormal byte * 2^-24, device_core.hpp wide_node_test): x and y as the upper halves of their floats
+//         (a power of two has no other bits), z as the float.  A node is its first THREE units: the kernel does not fetch the fourth (a node step costs
+//         three 16-byte loads per lane instead of four; every load instruction of a step is ~1 % of the frame, profiles/r4_o_node_three_units.txt)
 //   leaf  {min.xyz, slot | kind << 26} {max.xyz, v0.x} {v0.yz, e1.xy} {e1.z, e2.xyz}      (the walk array's leaf record)
 // A node's children are contiguous records.  The kernel keeps, per lane, the children of a node that were entered
 // but not yet visited as ONE stack word: first child's index << 8 | leaf mask << 4 | pending mask.
+// (host-side readers of a node record's words: wide_builder.cpp writes them, tools/study_wide_walk.cpp reads them)
+inline uint32_t wide_node_first_child(const uint32_t* w) { return w[3] & 0xffffffu; }
+inline uint32_t wide_node_valid(const uint32_t* w) { return (w[3] >> 24) & 15u; }
+inline uint32_t wide_node_leaf_mask(const uint32_t* w) { return w[3] >> 28; }
+inline uint32_t wide_node_lo(const uint32_t* w, int axis) { return w[4 + axis]; }
+inline uint32_t wide_node_hi(const uint32_t* w, int axis) { return w[7 + axis]; }
+inline uint32_t wide_node_scale24_bits(const uint32_t* w, int axis) { return axis == 0 ? w[10] << 16 : (axis == 1 ? w[10] & 0xffff0000u : w[11]); }      // bits of scale * 2^24
 constexpr int WIDE_UNITS = 4;
 constexpr int WIDE_INDEX_BITS = 24;                   // records < 2^24 (1 GiB of them)
 constexpr int WIDE_STACK = 16;                        // stack words per lane kept in LDS (one more lives in a register)

@@ -363,15 +363,22 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
     for (int a = 0; a < 3; a++) pmax = fmaxf(pmax, fmaxf(fabsf(origin[a]), fabsf(fmaf(255.0f, scale[a], origin[a]))));
     uint32_t words[WIDE_UNITS * 4];
     memset(words, 0, sizeof(words));
-    for (int a = 0; a < 3; a++) { words[a] = fbits(origin[a]); words[4 + a] = fbits(ldexpf(scale[a], 24)); }      // the record holds scale * 2^24 (device_core.hpp DR_NODE_V2)
-    words[3] = 0x80000000u | (uint32_t)base;
-    words[7] = ((1u << w.n) - 1u) | (leafmask << 4);
+    // (device_layout.h: the node is the record's first three units)
+    uint32_t s24[3];
+    for (int a = 0; a < 3; a++) {
+      words[a] = fbits(origin[a]);
+      s24[a] = fbits(ldexpf(scale[a], 24));      // the record holds scale * 2^24 (device_core.hpp wide_node_test)
+      if (s24[a] & 0xffffu) return false;        // (a power of two: nothing below the upper half)
+    }
+    words[3] = (uint32_t)base | (((1u << w.n) - 1u) << 24) | (leafmask << 28);
     for (int a = 0; a < 3; a++) {
       uint32_t wl = 0, wh = 0;
       for (int k = 0; k < w.n; k++) { wl |= (uint32_t)lo[k][a] << (8 * k); wh |= (uint32_t)hi[k][a] << (8 * k); }
       for (int k = w.n; k < 4; k++) wl |= 255u << (8 * k);      // unused child: inverted box (and cleared valid bit)
-      words[8 + a] = wl; words[11 + a] = wh;
+      words[4 + a] = wl; words[7 + a] = wh;
     }
+    words[10] = (s24[0] >> 16) | (s24[1] & 0xffff0000u);
+    words[11] = s24[2];
     memcpy(&rec[it.at * WIDE_UNITS], words, sizeof(words));
     n_nodes++;
     for (int k = w.n - 1; k >= 0; k--) {

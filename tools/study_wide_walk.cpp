@@ -58,17 +58,18 @@ static void wide_hit(const std::vector<DevUnit>& rec, float pmax, const float o[
       }
     } else {
       ws.nodes++;
-      const unsigned base = w[3] & 0xffffffu, valid = w[7] & 15u, leafmask = (w[7] >> 4) & 15u;
+      const unsigned base = wide_node_first_child(w), valid = wide_node_valid(w), leafmask = wide_node_leaf_mask(w);
       // the kernel's folded test (wide_node_test) and, as a check, the plain decode-and-slab test it must cover
       unsigned mask_plain = 0, key = 0xffffffffu; float dist[4] = {0, 0, 0, 0};
-      u32x4 RA, RB, RC, RD; memcpy(&RA, w, 16); memcpy(&RB, w + 4, 16); memcpy(&RC, w + 8, 16); memcpy(&RD, w + 12, 16);
-      unsigned mask = wide_node_test(RA, RB, RC, RD, mk(inv[0], inv[1], inv[2]), wr, best_t, key);      // the kernel's test
+      u32x4 RA, RB, RC; memcpy(&RA, w, 16); memcpy(&RB, w + 4, 16); memcpy(&RC, w + 8, 16);
+      unsigned mask = wide_node_test(RA, RB, RC, mk(inv[0], inv[1], inv[2]), wr, best_t, key);      // the kernel's test
       float nearest_plain = INFINITY;
       for (int k = 0; k < 4; k++) {
         float mn[3], mx[3];
         for (int a = 0; a < 3; a++) {
-          const float ql = (float)((w[8 + a] >> (8 * k)) & 255u), qh = (float)((w[11 + a] >> (8 * k)) & 255u);
-          const float sc = f[4 + a] * 0x1p-24f;      // the record holds scale * 2^24
+          const float ql = (float)((wide_node_lo(w, a) >> (8 * k)) & 255u), qh = (float)((wide_node_hi(w, a) >> (8 * k)) & 255u);
+          const uint32_t sb = wide_node_scale24_bits(w, a); float s24; memcpy(&s24, &sb, 4);
+          const float sc = s24 * 0x1p-24f;      // the record holds scale * 2^24
           mn[a] = fmaf(ql, sc, f[a]); mx[a] = fmaf(qh, sc, f[a]);
         }
         float dplain;
@@ -109,7 +110,7 @@ static void exact_boxes(const std::vector<DevUnit>& rec, size_t idx, bool leaf, 
   const float* f = reinterpret_cast<const float*>(w);
   float* b = &bx[idx * 6];
   if (leaf) { for (int a = 0; a < 3; a++) { b[a] = f[a]; b[3 + a] = f[4 + a]; } return; }
-  const unsigned base = w[3] & 0xffffffu, valid = w[7] & 15u, leafmask = (w[7] >> 4) & 15u;
+  const unsigned base = wide_node_first_child(w), valid = wide_node_valid(w), leafmask = wide_node_leaf_mask(w);
   for (int a = 0; a < 3; a++) { b[a] = INFINITY; b[3 + a] = -INFINITY; }
   for (int k = 0; k < 4; k++) if (valid >> k & 1) {
     exact_boxes(rec, base + k, leafmask >> k & 1, bx);
@@ -136,7 +137,7 @@ static void exact_hit(const std::vector<DevUnit>& rec, const std::vector<float>&
       continue;
     }
     nodes++;
-    const unsigned base = w[3] & 0xffffffu, valid = w[7] & 15u, leafmask = (w[7] >> 4) & 15u;
+    const unsigned base = wide_node_first_child(w), valid = wide_node_valid(w), leafmask = wide_node_leaf_mask(w);
     struct C { float d; unsigned idx; bool leaf; } c[4]; int n = 0;
     for (int k = 0; k < 4; k++) if (valid >> k & 1) {
       float dk;
