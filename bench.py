@@ -565,8 +565,9 @@ def main():
             "kernel": {"V": own["node_visits"] / own["rays"], "L": own["prim_tests"] / own["rays"],
                        "bytes": kbytes * frames / own["rays"]},
         },
-        # What binds this kernel is VALU issue: one more VALU instruction per node step costs its full 2.4-cycle issue time,
-        # one more 16-byte fetch per lane and step costs 1.4 % (tools/exp_variant.sh).  So the headline is the VALU
+        # What binds this kernel is VALU issue -- one more VALU instruction per node step costs its full 2.4-cycle issue time -- with the CUs' texture
+        # addressers as a second nearly full resource (busy 59 % of the launch: one cache access per active lane and load, profiles/r4_o_node_three_units.txt;
+        # one more load per lane and step costs 1-5 %).  The headline is the VALU
         # roofline on USEFUL work: active-lane VALU operations per second against 256 CUs x 4 SIMDs x 32 lanes x 2.4 GHz.
         # The HBM figures SURVEY 8(d) defines are kept beside it: `hbm` (bytes that reach the fabric, PMC) and `hbm_algorithmic`
         # (the reference traversal's bytes, mostly served by L1/L2/Infinity Cache -- it may exceed the HBM peak).
@@ -580,7 +581,7 @@ def main():
                                 "note": "SURVEY 8(d): 32 V + 36 L + 128 S + 4 T + 12 W H with the REFERENCE traversal's visit counts; these bytes are what the "
                                         "reference algorithm asks for, not what reaches HBM"},
             "gather": None,
-            "kernel_own_visit_bytes_per_launch": 64 * own["node_visits"] / frames * frames_per_launch,
+            "kernel_own_visit_bytes_per_launch": 64 * own["node_visits"] / frames * frames_per_launch,      # records visited x their 64-byte stride (a node's fourth 16 bytes are not fetched)
             "launch_ms": launch_ms,
             "frames_per_launch": frames_per_launch,
             "note": "launch_ms: HIP events on the library's render stream in the MEDIAN repeat of the timed region (the repeat `value` is quoted on); "
