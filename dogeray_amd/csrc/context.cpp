@@ -26,8 +26,8 @@ struct dr_context {
   bool pending[2] = {false, false}; uint64_t pending_frames[2] = {0, 0}, pending_samples[2] = {0, 0}; int pending_next = 0;
   // resident scene
   DevUnit* walk = nullptr; size_t walk_bytes = 0;
-  DevUnit* wide = nullptr; size_t wide_bytes = 0; int wide_depth = 0, wide_nodes = 0; float wide_pmax = 0;   // null: scene not representable (threaded walk is used)
-  int wide_tree = 1;        // structure of the wide walk's tree: 1 binned SAH (default), 0 the reference's topology collapsed
+  DevUnit* wide = nullptr; size_t wide_bytes = 0; int wide_depth = 0, wide_nodes = 0; float wide_pmax = 0; WideMu wide_mu = {0, 0, 0};   // null: scene not representable (threaded walk is used)
+  int wide_tree = 2;        // structure of the wide walk's tree: 2 binned SAH with small triangles entered by their own bounds (default), 1 binned SAH over the reference's leaf boxes, 0 the reference's topology collapsed
   DevPair* pairs = nullptr;
   DevPrim* prims = nullptr;
   DevShade* shade = nullptr;
@@ -149,7 +149,7 @@ int make_params(dr_context* c, const float* st, int W, int H, float background, 
   if (P.backtex >= c->n_tex) { set_error("backtex refers to a texture that is not loaded"); return DR_ERR_INVALID; }
   memcpy(c->cur_settings, st, sizeof(c->cur_settings));
   P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims; P.shade = c->shade; P.tex = c->tex; P.texels = c->texels;
-  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax;
+  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax; P.wide_mu = c->wide_mu;
   P.counters = c->counters;
   P.wave_log = c->wave_log_on ? c->wave_log : nullptr;
   P.coop_steps = c->coop_steps; P.coop_rounds = c->coop_rounds; P.split_parts = c->split_parts;
@@ -285,7 +285,7 @@ int set_option(dr_context* c, const std::string& name, int v) {
   else if (name == "feedback") { c->feedback = v != 0; c->order_valid = false; }
   else if (name == "order_follows_camera") { c->order_follows_camera = v != 0; }
   else if (name == "feedback_every") { if (v < 1) goto bad; c->feedback_every = v; }
-  else if (name == "wide_tree") { if (v != 0 && v != 1) goto bad; c->wide_tree = v; }      // takes effect at the next dr_context_upload_scene
+  else if (name == "wide_tree") { if (v < 0 || v > 2) goto bad; c->wide_tree = v; }      // takes effect at the next dr_context_upload_scene
   else { set_error("unknown option '" + name + "'"); return DR_ERR_INVALID; }
   return DR_OK;
 bad:
@@ -459,7 +459,7 @@ int dr_context_upload_scene(dr_context* c, const dr_scene* s) {
   if ((rc = upload(c->walk, img.walk)) != DR_OK) return rc;
   c->walk_bytes = img.walk.size() * sizeof(DevUnit);
   if (c->wide) { (void)hipFree(c->wide); c->wide = nullptr; }
-  c->wide_bytes = 0; c->wide_depth = img.wide_depth; c->wide_nodes = img.wide_nodes; c->wide_pmax = img.wide_pmax;
+  c->wide_bytes = 0; c->wide_depth = img.wide_depth; c->wide_nodes = img.wide_nodes; c->wide_pmax = img.wide_pmax; c->wide_mu = img.wide_mu;
   if (!img.wide.empty()) {
     if ((rc = upload(c->wide, img.wide)) != DR_OK) return rc;
     c->wide_bytes = img.wide.size() * sizeof(DevUnit);
@@ -1097,7 +1097,7 @@ int dr_context_probe_trace(dr_context* c, const float settings13[13], int W, int
   if ((rc = cursor.alloc(1)) != DR_OK || (rc = out.alloc((size_t)n * 2)) != DR_OK || (rc = ref.alloc((size_t)n * 2)) != DR_OK) return rc;
   RenderParams P;
   memset(&P, 0, sizeof(P));
-  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax;
+  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax; P.wide_mu = c->wide_mu;
   // 2. the probe, timed (one warm-up, then the best of three)
   float best = 1e30f;
   for (int rep = 0; rep < 4; rep++) {
@@ -1231,7 +1231,7 @@ int dr_kat_hit(dr_context* c, int n, const float* o, const float* d, float* t, i
   RenderParams P;
   memset(&P, 0, sizeof(P));
   P.walk = c->walk; P.walk_bytes = (uint32_t)c->walk_bytes; P.pairs = c->pairs; P.prims = c->prims;
-  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax;
+  P.wide = c->wide; P.wide_bytes = (uint32_t)c->wide_bytes; P.wide_pmax = c->wide_pmax; P.wide_mu = c->wide_mu;
   launch_kat_hit(c->stream, P, traversal_of(c), n, bo.p, bd.p, bt.p, bs.p, bv.p);
   HIP_TRY(hipStreamSynchronize(c->stream));
   KAT_DO(bt.get(t, (size_t)n));

@@ -598,11 +598,33 @@ __device__ __forceinline__ WideRay wide_ray_none() {      // a lane without a ra
   w.inv = w.on = w.of = mk(0, 0, 0);
   return w;
 }
-__device__ __forceinline__ WideRay wide_ray(V3 o, V3 inv, float pmax) {
+// The position margin of a ray when small triangles sit in the tree with their own bounds (WideMu, wide_tree = 2; proof: DESIGN.md 4.10).  The reference
+// accepts a hit when Moeller-Trumbore, in floats, says so AND the leaf's padded box is entered; a tree built over the padded boxes visits every such leaf.
+// Built over the triangles' own bounds B it still does if every box test is loosened by mu, where mu bounds how far outside B (per axis, and along the ray
+// in units of position) a ray can pass and still be ACCEPTED by the float test.  With u = 2^-24, |a| >= 1e-4 for every accepted hit (hit_tri's cut-off),
+// s = o - v0, E = |e1| |e2|, L = |e1| + |e2| (Euclidean norms):
+//     |u_f - u^| , |v_f - v^| <= 6.03e-4 |d| |e| (8.52 |s| + 7.11 |e'|) + 2.02 u      (u^, v^, t^: the exact solution of o + t d = v0 + u e1 + v e2)
+//     |t_f - t^| |d|          <= 6.03e-4 E |d| (8.52 |s| + 7.11 |t_f| |d|) + 2.02 u |t_f| |d|,   |t_f| |d| <= |s| + 1.1 L + 0.01
+// so the exact ray is inside B + mu_pos at t^, and B + mu_pos + |d| |t_f - t^| is entered no later than t_f and left after it, for
+//     mu = |d| E (0.0197 |s| + 0.0090 L + 4.3e-5) + 1.3e-7 |s| + 4.5e-7 L      -- rounded up below to 0.02, 0.014, 1e-4 and 2^-21 (|s| + 4 L + 1), |s| <= |o| + |v0|.
+// Above the cap the margin is the reference's own padding (B + 0.01 (1 + 2^-16) + the absolute term encloses the padded box): such rays -- camera rays with a
+// long direction vector, mostly -- walk the tree exactly as they would the tree over padded boxes.  Rays or scenes beyond 2^30 take the cap too (no overflow
+// inside the bound's arithmetic below that).
+__device__ __forceinline__ float wide_ray_margin(V3 o, V3 d, WideMu mu) {
+  if (!(mu.e > 0.0f)) return 0.0f;
+  const float abs_term = (__builtin_sqrtf(dot(o, o)) * 1.0001f + mu.v + 4.0f * mu.l + 1.0f) * 0x1p-21f;
+  const float cap = 0.01f * (1.0f + 0x1p-16f) + abs_term;
+  const float dn = __builtin_sqrtf(dot(d, d)) * 1.0001f, s = __builtin_sqrtf(dot(o, o)) * 1.0001f + mu.v;
+  const float m = dn * mu.e * 1.0001f * (0.02f * s + 0.014f * mu.l + 1e-4f) * 1.0001f + abs_term;
+  const bool tame = dn <= 0x1p30f && s <= 0x1p30f && dn * mu.e <= 2.0f;      // (false for NaNs)
+  return (tame && m < cap) ? m : cap;
+}
+__device__ __forceinline__ WideRay wide_ray(V3 o, V3 d, V3 inv, float pmax, WideMu mu) {
   WideRay w;
-  auto one = [pmax](float oa, float ia, float& ic, float& on, float& of) {
+  const float extra = wide_ray_margin(o, d, mu);
+  auto one = [pmax, extra](float oa, float ia, float& ic, float& on, float& of) {
     ic = __builtin_fminf(__builtin_fmaxf(ia, -0x1p60f), 0x1p60f);                    // NaN -> -2^60, and the margin below is NaN
-    const float k = __builtin_fmaf(pmax + __builtin_fabsf(oa), 0x1p-21f, 0x1p-40f);
+    const float k = __builtin_fmaf(pmax + __builtin_fabsf(oa), 0x1p-21f, 0x1p-40f) + extra;
     const float ai = __builtin_fabsf(ic);
     const float m = (ia == ia && ai > 0x1p-60f && __builtin_fabsf(oa) < 0x1p60f) ? ai * k : __builtin_nanf("");
     const float p = oa * ic;
@@ -792,12 +814,12 @@ __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, 
   wide_leaf_compute<COUNT>(r, o, d, inv, sg, tr, ws, stack, c);
 }
 template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, float pmax, V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [word * 64] */) {
+__device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, float pmax, WideMu mu, V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [word * 64] */) {
   Trav tr;
   trav_begin(tr);
   WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
   const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const WideRay wr = wide_ray(o, inv, pmax);
+  const WideRay wr = wide_ray(o, d, inv, pmax, mu);
   if (COUNT) c.rays++;
   while (tr.node >= 0) {
     const WideRec r = wide_fetch(wide, tr.node);

@@ -50,6 +50,13 @@ inline uint32_t wide_node_leaf_mask(const uint32_t* w) { return w[3] >> 28; }
 inline uint32_t wide_node_lo(const uint32_t* w, int axis) { return w[4 + axis]; }
 inline uint32_t wide_node_hi(const uint32_t* w, int axis) { return w[7 + axis]; }
 inline uint32_t wide_node_scale24_bits(const uint32_t* w, int axis) { return axis == 0 ? w[10] << 16 : (axis == 1 ? w[10] & 0xffff0000u : w[11]); }      // bits of scale * 2^24
+// wide_tree = 2 (default): small triangles enter the tree with their OWN bounds instead of the reference's leaf box (their bounds padded by 0.01), and every ray
+// carries the position margin that makes up for it (device_core.hpp wide_ray; DESIGN.md 4.10 has the proof).  e = 0: every leaf entered with the reference's box.
+struct WideMu {
+  float e;      // largest |e1| |e2| of the triangles that entered with their own bounds (Euclidean norms)
+  float l;      // largest |e1| + |e2| of them
+  float v;      // largest |v0| of them
+};
 constexpr int WIDE_UNITS = 4;
 constexpr int WIDE_INDEX_BITS = 24;                   // records < 2^24 (1 GiB of them)
 constexpr int WIDE_STACK = 16;                        // stack words per lane kept in LDS (one more lives in a register)
@@ -145,6 +152,7 @@ struct RenderParams {
   int32_t regions;                // persistent kernel: number of tile queues (1, or 8 = one per XCD)
   uint32_t out_frame_stride;      // int32 words between the output buffers of two frames of a batch (0: one buffer for all: accumulation)
   int32_t region_start[9];        // identity order: region r owns tiles [region_start[r], region_start[r+1])
+  WideMu wide_mu;                 // wide walk: the margin's scene constants (e = 0: none)
 };
 
 }  // namespace dr

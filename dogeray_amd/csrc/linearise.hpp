@@ -18,6 +18,7 @@ struct DeviceImage {
   std::vector<DevUnit> wide;       // wide walk records, empty if the scene is not representable
   int wide_depth = 0, wide_nodes = 0;
   float wide_pmax = 0;
+  WideMu wide_mu = {0, 0, 0};      // wide_tree = 2: the margin's scene constants (device_layout.h)
 };
 
 // wide_builder.cpp: the 4-way traversal structure over the reference's leaves (device_layout.h "wide walk")
@@ -25,11 +26,13 @@ struct WideImage {
   std::vector<DevUnit> rec;        // WIDE_UNITS per record, root = record 0
   int depth = 0, nodes = 0, leaves = 0;
   float pmax = 0;                  // largest |decoded plane coordinate| over all nodes
+  WideMu mu = {0, 0, 0};           // tree_mode 2: constants of the rays' margin (e = 0: every leaf entered with the reference's box)
 };
-// tree_mode 1: binned-SAH tree (default), 0: the reference's topology collapsed.  false = not representable.
+// tree_mode 2 (default): binned-SAH tree, small triangles entered with their own bounds (the rays carry a margin); 1: the same over the reference's leaf boxes;
+// 0: the reference's topology collapsed.  false = not representable.
 bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, const std::vector<DevPrim>& prims, int tree_mode,
                 int nthreads, WideImage& out);
 
-int linearise(const HostScene& sc, DeviceImage& img, int wide_tree_mode = 1);
+int linearise(const HostScene& sc, DeviceImage& img, int wide_tree_mode = 2);
 
 }  // namespace dr

@@ -10,7 +10,8 @@
 // traversal structure (266 node visits per ray on the city scene).  This file builds a better one:
 //
 //   1. a binary tree over the leaf boxes, either by binned surface-area heuristic (default) or by copying
-//      the reference's topology (option wide_tree = 0, for comparison);
+//      the reference's topology (option wide_tree = 0, for comparison); wide_tree = 2 (default): the SAH tree over the small triangles' OWN bounds
+//      instead of their padded leaf boxes, with a per-ray margin in the kernel that keeps the set of accepted hits the reference's (step 0 below);
 //   2. collapsed into nodes with up to four children (largest child opened first);
 //   3. laid out as 64-byte records, children of a node contiguous, child boxes quantised to 8 bits on a
 //      per-node grid {origin, power-of-two scale; the record stores scale * 2^24} and rounded OUTWARD; every decoded plane is checked here
@@ -274,6 +275,52 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
     if (!finite_box(b.min, b.max)) return false;
     memcpy(leaf[(size_t)s].mn, b.min, 12); memcpy(leaf[(size_t)s].mx, b.max, 12);
   }
+  // ---- 0. the boxes the tree is built over and culls with.  tree_mode 2: a small triangle enters with its OWN bounds (the record's v0, v0 + e1, v0 + e2,
+  // rounded outward) instead of the reference's leaf box, which is those bounds padded by 0.01 (K:353-354) -- 2.9 times the footprint of a 0.028-wide triangle --;
+  // the rays make up for it with a margin that is a multiple of E = max |e1| |e2| over these triangles (device_core.hpp wide_ray_margin).
+  // "Small": the margin of a unit-length ray from anywhere in the scene stays below 0.003.  Other primitives keep the reference's box.
+  std::vector<Box> cull(leaf);
+  out.mu = WideMu{0, 0, 0};
+  if (tree_mode == 2) {
+    double vmax_all = 0;
+    for (int s = 0; s < N; s++) {
+      const DevPrim& p = prims[(size_t)s];
+      if (p.type == 2) vmax_all = std::max(vmax_all, std::sqrt((double)p.v0[0] * p.v0[0] + (double)p.v0[1] * p.v0[1] + (double)p.v0[2] * p.v0[2]));
+    }
+    const double e_cut = 0.003 / (0.02 * (2.0 * vmax_all + 1.0)), l_cut = std::max(1.0, vmax_all);
+    double e_s = 0, l_s = 0, v_s = 0;
+    int chosen = 0;
+    if (vmax_all < 0x1p30) {
+      for (int s = 0; s < N; s++) {
+        const DevPrim& p = prims[(size_t)s];
+        if (p.type != 2) continue;
+        const double v0[3] = {p.v0[0], p.v0[1], p.v0[2]}, e1[3] = {p.e1x, p.e1y, p.e1z}, e2[3] = {p.e2x, p.e2y, p.e2z};
+        const double n1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), n2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        if (!(n1 * n2 <= e_cut && n1 + n2 <= l_cut)) continue;      // (a NaN edge stays with the reference's box)
+        Box t;
+        bool inside = true;
+        for (int a = 0; a < 3; a++) {
+          const double lo = std::min(v0[a], std::min(v0[a] + e1[a], v0[a] + e2[a])), hi = std::max(v0[a], std::max(v0[a] + e1[a], v0[a] + e2[a]));      // (exact: sums of two floats)
+          float fl = (float)lo, fh = (float)hi;
+          if ((double)fl > lo) fl = nextafterf(fl, -INFINITY);
+          if ((double)fh < hi) fh = nextafterf(fh, INFINITY);
+          t.mn[a] = fl; t.mx[a] = fh;
+          // only ever SHRINK the reference's box (v0 + e1 is v1 up to a rounding of the edge: it cannot leave the padding)
+          if (!(fl >= leaf[(size_t)s].mn[a] && fh <= leaf[(size_t)s].mx[a])) inside = false;
+        }
+        if (!inside) continue;
+        cull[(size_t)s] = t;
+        chosen++;
+        e_s = std::max(e_s, n1 * n2); l_s = std::max(l_s, n1 + n2);
+        v_s = std::max(v_s, std::sqrt(v0[0] * v0[0] + v0[1] * v0[1] + v0[2] * v0[2]));
+      }
+    }
+    if (chosen > 0) {
+      // (rounded up into floats; e > 0 is what switches the rays' margin on)
+      auto up = [](double x) { float f = (float)x; if ((double)f < x) f = nextafterf(f, INFINITY); return f; };
+      out.mu = WideMu{std::max(up(e_s), 0x1p-100f), up(l_s), up(v_s)};
+    }
+  }
 
   // ---- 1. binary tree
   std::vector<BNode> bn;
@@ -302,18 +349,18 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
       me.box.clear();
       for (int c = 0; c < 2; c++) {
         const int ch = b.children[c];
-        if (sc.bvh[(size_t)ch].end) { me.child[c] = ~slot_of[(size_t)ch]; me.box.grow(leaf[(size_t)slot_of[(size_t)ch]]); }
+        if (sc.bvh[(size_t)ch].end) { me.child[c] = ~slot_of[(size_t)ch]; me.box.grow(cull[(size_t)slot_of[(size_t)ch]]); }
         else { me.child[c] = id_of[(size_t)ch]; me.box.grow(bn[(size_t)id_of[(size_t)ch]].box); }
       }
     }
     // the reference tree is a median split: its depth is ceil(log2 N) <= 26
   } else {
-    SahBuilder sb(leaf);
+    SahBuilder sb(cull);
     sb.cen.resize((size_t)N * 3);
     sb.idx.resize((size_t)N);
     for (int s = 0; s < N; s++) {
       sb.idx[(size_t)s] = s;
-      for (int a = 0; a < 3; a++) sb.cen[(size_t)s * 3 + a] = 0.5f * leaf[(size_t)s].mn[a] + 0.5f * leaf[(size_t)s].mx[a];
+      for (int a = 0; a < 3; a++) sb.cen[(size_t)s * 3 + a] = 0.5f * cull[(size_t)s].mn[a] + 0.5f * cull[(size_t)s].mx[a];
     }
     sb.nodes.resize((size_t)N - 1);
     if (nthreads <= 0) nthreads = usable_threads();
@@ -326,10 +373,10 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
 
   // ---- 2. collapse; keep the area-guided collapse if it fits the kernel's stack, else two levels per node
   bool fixed_levels = false;
-  int depth = wide_depth(bn, leaf, false);
+  int depth = wide_depth(bn, cull, false);
   if (depth > WIDE_MAX_DEPTH) {
     fixed_levels = true;
-    depth = wide_depth(bn, leaf, true);
+    depth = wide_depth(bn, cull, true);
     if (depth > WIDE_MAX_DEPTH) return false;
   }
 
@@ -346,14 +393,14 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
   while (!st.empty()) {
     const Item it = st.back();
     st.pop_back();
-    collapse(bn, leaf, it.b, fixed_levels, w);
+    collapse(bn, cull, it.b, fixed_levels, w);
     const size_t base = rec.size() / WIDE_UNITS;
     if (base + (size_t)w.n > ((size_t)1 << WIDE_INDEX_BITS)) return false;
     rec.resize(rec.size() + (size_t)w.n * WIDE_UNITS);
     Box cb[4];
     uint32_t leafmask = 0;
     for (int k = 0; k < w.n; k++) {
-      if (w.child[k] < 0) { cb[k] = leaf[(size_t)~w.child[k]]; leafmask |= 1u << k; }
+      if (w.child[k] < 0) { cb[k] = cull[(size_t)~w.child[k]]; leafmask |= 1u << k; }
       else cb[k] = bn[(size_t)w.child[k]].box;
     }
     float origin[3], scale[3];

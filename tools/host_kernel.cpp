@@ -40,7 +40,7 @@ void render_columns(const RenderParams& P, int traversal, int first, int step, C
       for (int lane = 0; lane < 64; lane++) {                       // lane l of a tile is pixel (l >> 3, l & 7), as in the kernels
         const int x = bx * 8 + (lane >> 3), y = by * 8 + (lane & 7);
         if (traversal == DR_TRAVERSAL_WIDE && P.wide) {
-          auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_wide<COUNT>(wide, P.wide_pmax, o, d, cc, stack.data()); };
+          auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_wide<COUNT>(wide, P.wide_pmax, P.wide_mu, o, d, cc, stack.data()); };
           render_pixel<COUNT>(P, closest, x, y, c);
         } else if (traversal == DR_TRAVERSAL_ORDERED) {
           auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_ordered<COUNT>(P.pairs, P.prims, o, d, cc, stack.data()); };
@@ -165,7 +165,7 @@ int hk_render(void* hv, const float* settings13, int W, int H, float background,
   const DeviceImage& img = h->img;
   if (P.backtex >= (int)img.tex.size()) { hk_err = "backtex refers to a texture that is not loaded"; return -1; }
   P.walk = img.walk.data(); P.walk_bytes = (uint32_t)(img.walk.size() * sizeof(DevUnit));
-  P.wide = img.wide.empty() ? nullptr : img.wide.data(); P.wide_bytes = (uint32_t)(img.wide.size() * sizeof(DevUnit)); P.wide_pmax = img.wide_pmax;
+  P.wide = img.wide.empty() ? nullptr : img.wide.data(); P.wide_bytes = (uint32_t)(img.wide.size() * sizeof(DevUnit)); P.wide_pmax = img.wide_pmax; P.wide_mu = img.wide_mu;
   P.pairs = img.pairs.data(); P.prims = img.prims.data(); P.shade = img.shade.data(); P.tex = img.tex.data(); P.texels = img.texels.data();
   P.out = out;
   P.accumulate = 0;

@@ -35,9 +35,9 @@ static float tri(const float o[3], const float d[3], const float* v0, const floa
 
 struct WideStats { long nodes = 0, leaves = 0, tests = 0, maxsp = 0, cull_nodes = 0, cull_leaves = 0, cull_entry = 0, extra_children = 0, leafkids[5] = {0, 0, 0, 0, 0}; };
 
-static void wide_hit(const std::vector<DevUnit>& rec, float pmax, const float o[3], const float d[3], const float inv[3], float& best_t, int& best_slot, WideStats& ws) {
+static void wide_hit(const std::vector<DevUnit>& rec, float pmax, WideMu mu, const float o[3], const float d[3], const float inv[3], float& best_t, int& best_slot, WideStats& ws) {
   best_t = 10000.0f; best_slot = -1;      // trav_begin
-  const WideRay wr = wide_ray(mk(o[0], o[1], o[2]), mk(inv[0], inv[1], inv[2]), pmax);
+  const WideRay wr = wide_ray(mk(o[0], o[1], o[2]), mk(d[0], d[1], d[2]), mk(inv[0], inv[1], inv[2]), pmax, mu);
   unsigned stack[WIDE_STACK]; int sp = 0; unsigned top = 0;
   float sd[WIDE_STACK + 1][4]; float topd[4] = {0, 0, 0, 0};   // study only: entry distance of every pending child
   unsigned cur = 0;   // index << 1 | leaf
@@ -187,7 +187,7 @@ int main(int argc, char** argv) {
               float tt = p.type == 2 ? tri(o, d, p.v0, e1, e2) : -1; if (tt > 0 && tt < 10000.0f && tt < best) { best = tt; bs = slot[node]; } } node = b.miss_node; }
           else { bin_int++; node = h ? b.hit_node : b.miss_node; } } }
       float wb; int wsl;
-      wide_hit(img.wide, img.wide_pmax, o, d, inv, wb, wsl, ws);
+      wide_hit(img.wide, img.wide_pmax, img.wide_mu, o, d, inv, wb, wsl, ws);
       exact_hit(img.wide, bx, o, d, inv, ex_nodes, ex_leaves);
       if (wsl != bs || (bs >= 0 && wb != best)) { printf("MISMATCH ray %d bounce %d: wide %d %g vs reference %d %g\n", r, bounce, wsl, wb, bs, best); return 1; }
       rays++;
