@@ -26,7 +26,7 @@ struct dr_context {
   bool pending[2] = {false, false}; uint64_t pending_frames[2] = {0, 0}, pending_samples[2] = {0, 0}; int pending_next = 0;
   // resident scene
   DevUnit* walk = nullptr; size_t walk_bytes = 0;
-  DevUnit* wide = nullptr; size_t wide_bytes = 0; int wide_depth = 0, wide_nodes = 0; float wide_pmax = 0; WideMu wide_mu = {0, 0, 0};   // null: scene not representable (threaded walk is used)
+  DevUnit* wide = nullptr; size_t wide_bytes = 0; int wide_depth = 0, wide_nodes = 0; float wide_pmax = 0; WideMu wide_mu = {0, 0, 0}; int wide_own_bounds = 0;   // null: scene not representable (threaded walk is used)
   int wide_tree = 2;        // structure of the wide walk's tree: 2 binned SAH with small triangles entered by their own bounds (default), 1 binned SAH over the reference's leaf boxes, 0 the reference's topology collapsed
   DevPair* pairs = nullptr;
   DevPrim* prims = nullptr;
@@ -459,7 +459,7 @@ int dr_context_upload_scene(dr_context* c, const dr_scene* s) {
   if ((rc = upload(c->walk, img.walk)) != DR_OK) return rc;
   c->walk_bytes = img.walk.size() * sizeof(DevUnit);
   if (c->wide) { (void)hipFree(c->wide); c->wide = nullptr; }
-  c->wide_bytes = 0; c->wide_depth = img.wide_depth; c->wide_nodes = img.wide_nodes; c->wide_pmax = img.wide_pmax; c->wide_mu = img.wide_mu;
+  c->wide_bytes = 0; c->wide_depth = img.wide_depth; c->wide_nodes = img.wide_nodes; c->wide_pmax = img.wide_pmax; c->wide_mu = img.wide_mu; c->wide_own_bounds = img.wide_own_bounds;
   if (!img.wide.empty()) {
     if ((rc = upload(c->wide, img.wide)) != DR_OK) return rc;
     c->wide_bytes = img.wide.size() * sizeof(DevUnit);
@@ -516,6 +516,7 @@ int dr_context_get_option(const dr_context* c, const char* name, int* value) {
   else if (n == "pipe_group") *value = c->pipe_group;
   else if (n == "tree_depth") *value = c->tree_depth;
   else if (n == "wide_tree") *value = c->wide_tree;
+  else if (n == "wide_own_bounds") *value = c->wide ? c->wide_own_bounds : 0;
   else if (n == "wide_depth") *value = c->wide ? c->wide_depth : 0;          // 0: the scene has no wide structure
   else if (n == "wide_nodes") *value = c->wide ? c->wide_nodes : 0;
   else if (n == "traversal") *value = traversal_of(c);                        // the traversal launches really use

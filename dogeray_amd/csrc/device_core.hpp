@@ -604,9 +604,9 @@ __device__ __forceinline__ WideRay wide_ray_none() {      // a lane without a ra
 // in units of position) a ray can pass and still be ACCEPTED by the float test.  With u = 2^-24, |a| >= 1e-4 for every accepted hit (hit_tri's cut-off),
 // s = o - v0, E = |e1| |e2|, L = |e1| + |e2| (Euclidean norms):
 //     |u_f - u^| , |v_f - v^| <= 6.03e-4 |d| |e| (8.52 |s| + 7.11 |e'|) + 2.02 u      (u^, v^, t^: the exact solution of o + t d = v0 + u e1 + v e2)
-//     |t_f - t^| |d|          <= 6.03e-4 E |d| (8.52 |s| + 7.11 |t_f| |d|) + 2.02 u |t_f| |d|,   |t_f| |d| <= |s| + 1.1 L + 0.01
+//     |t_f - t^| |d|          <= 6.03e-4 E |d| (8.52 |s| + 7.11 |t_f| |d|) + 2.02 u |t_f| |d|,   |t_f| |d| <= |s| + L + 0.02
 // so the exact ray is inside B + mu_pos at t^, and B + mu_pos + |d| |t_f - t^| is entered no later than t_f and left after it, for
-//     mu = |d| E (0.0197 |s| + 0.0090 L + 4.3e-5) + 1.3e-7 |s| + 4.5e-7 L      -- rounded up below to 0.02, 0.014, 1e-4 and 2^-21 (|s| + 4 L + 1), |s| <= |o| + |v0|.
+//     mu = |d| E (0.0197 |s| + 0.0086 L + 8.6e-5) + 1.2e-7 |s| + 3.0e-7 L      -- rounded up below to 0.021, 0.015, 1.2e-4 and 2^-21 (|s| + 4 L + 1), |s| <= |o| + |v0|.
 // Above the cap the margin is the reference's own padding (B + 0.01 (1 + 2^-16) + the absolute term encloses the padded box): such rays -- camera rays with a
 // long direction vector, mostly -- walk the tree exactly as they would the tree over padded boxes.  Rays or scenes beyond 2^30 take the cap too (no overflow
 // inside the bound's arithmetic below that).
@@ -615,7 +615,7 @@ __device__ __forceinline__ float wide_ray_margin(V3 o, V3 d, WideMu mu) {
   const float abs_term = (__builtin_sqrtf(dot(o, o)) * 1.0001f + mu.v + 4.0f * mu.l + 1.0f) * 0x1p-21f;
   const float cap = 0.01f * (1.0f + 0x1p-16f) + abs_term;
   const float dn = __builtin_sqrtf(dot(d, d)) * 1.0001f, s = __builtin_sqrtf(dot(o, o)) * 1.0001f + mu.v;
-  const float m = dn * mu.e * 1.0001f * (0.02f * s + 0.014f * mu.l + 1e-4f) * 1.0001f + abs_term;
+  const float m = dn * mu.e * 1.0001f * (0.021f * s + 0.015f * mu.l + 1.2e-4f) * 1.0001f + abs_term;
   const bool tame = dn <= 0x1p30f && s <= 0x1p30f && dn * mu.e <= 2.0f;      // (false for NaNs)
   return (tame && m < cap) ? m : cap;
 }

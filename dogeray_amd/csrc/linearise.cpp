@@ -186,7 +186,7 @@ int linearise(const HostScene& sc, DeviceImage& img, int wide_tree_mode) {
       img.wide.swap(w.rec);
       img.wide_depth = w.depth;
       img.wide_nodes = w.nodes;
-      img.wide_pmax = w.pmax; img.wide_mu = w.mu;
+      img.wide_pmax = w.pmax; img.wide_mu = w.mu; img.wide_own_bounds = w.own_bounds;
     }
   }
 

@@ -19,6 +19,7 @@ struct DeviceImage {
   int wide_depth = 0, wide_nodes = 0;
   float wide_pmax = 0;
   WideMu wide_mu = {0, 0, 0};      // wide_tree = 2: the margin's scene constants (device_layout.h)
+  int wide_own_bounds = 0;         // ... and how many triangles entered the tree with their own bounds
 };
 
 // wide_builder.cpp: the 4-way traversal structure over the reference's leaves (device_layout.h "wide walk")
@@ -27,6 +28,7 @@ struct WideImage {
   int depth = 0, nodes = 0, leaves = 0;
   float pmax = 0;                  // largest |decoded plane coordinate| over all nodes
   WideMu mu = {0, 0, 0};           // tree_mode 2: constants of the rays' margin (e = 0: every leaf entered with the reference's box)
+  int own_bounds = 0;              // ... number of triangles entered with their own bounds
 };
 // tree_mode 2 (default): binned-SAH tree, small triangles entered with their own bounds (the rays carry a margin); 1: the same over the reference's leaf boxes;
 // 0: the reference's topology collapsed.  false = not representable.

@@ -184,13 +184,16 @@ int dr_context_set_traversal(dr_context* c, int mode);
  *   "reserve_cus"   persistent kernel: workgroups are launched for this many CUs fewer than the device has (0 = all; dr_group ranks may leave
  *                   room for the gather's copy / RCCL kernels beside the next batch's rendering)
  *   "wave_log"      1: short launches record begin / queue empty / end of every wave (dr_stats_wave_log)
- *   "wide_tree"     tree under the wide walk, read at dr_context_upload_scene: 1 (default) binned surface-area
- *                   heuristic over the leaf boxes, 0 the reference's own topology (K:1745-1861) collapsed 4-way
+ *   "wide_tree"     tree under the wide walk, read at dr_context_upload_scene: 2 (default) binned surface-area heuristic, small
+ *                   triangles entered with their own bounds instead of the reference's leaf box (those bounds padded by 0.01, K:353-354)
+ *                   and every ray carrying the margin that keeps the accepted hits the reference's; 1 the same tree
+ *                   over the reference's leaf boxes; 0 the reference's own topology (K:1745-1861) collapsed 4-way
  * The environment variable DOGERAY_OPTIONS="name=value,..." applies the same at context creation. */
 enum { DR_KERNEL_TILE = 0, DR_KERNEL_PERSISTENT = 1 };
 int dr_context_set_option(dr_context* c, const char* name, int value);
 /* Read a knob back (same names), or of the uploaded scene: "tree_depth" (reference tree), "wide_depth" / "wide_nodes"
- * (wide walk; 0 = not representable), "traversal" (the one launches really use). */
+ * (wide walk; 0 = not representable), "wide_own_bounds" (triangles that entered the wide tree with their own bounds, wide_tree = 2),
+ * "traversal" (the one launches really use). */
 int dr_context_get_option(const dr_context* c, const char* name, int* value);
 
 /* One CudaStarter call.  settings13 = { cam.xyz, look.xyz, aperture, focus, fov, max_depth,

@@ -24,6 +24,7 @@ def run_campaign(dr, orc, ctx, n_scenes, seed, workdir, texdir, texture_names, s
             path = random_scene(rng, nobj, os.path.join(workdir, "f%d.rts" % k), W=W, H=H, textures=texture_names)
             ps = dr.Scene.load(path, texdir); ps.build_bvh()
             osc = orc.Scene(path, texdir); osc.build_bvh()
+            ctx.set_option("wide_tree", int(rng.choice([2, 2, 2, 1, 0])))      # (read at upload)
             ctx.upload(ps)
             s = ps.settings()
             opts = {name: int(rng.choice(v)) for name, v in OPTION_POOL.items() if rng.random() < 0.6}
@@ -60,4 +61,5 @@ def run_campaign(dr, orc, ctx, n_scenes, seed, workdir, texdir, texture_names, s
                 log("scene %d ok (%d objects, %dx%d, %r)" % (k, nobj, W, H, opts))
     finally:
         for name, v in defaults.items(): ctx.set_option(name, v)
+        ctx.set_option("wide_tree", 2)
     return n_scenes, frames, bad

@@ -243,6 +243,44 @@ def test_deepest_wide_tree(dr, orc, ctx, tmp_path, n, ratio):
             assert stats["rays"] == rc["rays"] and stats["shades"] == rc["S"]
 
 
+def _scaled_rts(src, dst, k):
+    """A copy of a scene of triangles with every position (vertices, camera, look-at, focus distance) times k"""
+    out = []
+    for line in open(src).read().split("\n"):
+        c = line.split(",")
+        if line.startswith("*"):
+            for i in (1, 2, 3, 5, 6, 7, 8): c[i] = repr(float(c[i]) * k)
+        elif len(c) > 15 and c[3].strip() == "2":
+            for i in (0, 1, 2, 9, 10, 11, 13, 14, 15): c[i] = repr(float(c[i]) * k)
+        out.append(",".join(c))
+    open(dst, "w").write("\n".join(out))
+    return dst
+
+
+@pytest.mark.parametrize("scene", ["hf_small.rts", "hf_small.rts/10", "bunny_small.rts", "city_small.rts"])
+def test_wide_tree_over_the_triangles_own_bounds(dr, orc, ctx, synth, scene, tmp_path):
+    """wide_tree = 2 (default): small triangles enter the tree with their own bounds instead of the reference's padded leaf box and every ray carries the
+    margin of DESIGN.md 4.10 -- the frames stay the oracle's (camera rays and scattered rays, persistent and tile kernel, counting and plain build), with fewer
+    records per ray than the tree over the padded boxes wherever triangles qualified"""
+    path = os.path.join(synth["dir"], scene.split("/")[0])
+    if "/" in scene: path = _scaled_rts(path, str(tmp_path / "scaled.rts"), 1.0 / float(scene.split("/")[1]))      # (a tenth of the size: its triangles qualify)
+    visits = {}
+    try:
+        for tree in (2, 1):
+            ctx.set_option("wide_tree", tree)
+            for kernel in (1, 0):
+                g, r, stats, rc = _render_pair(dr, orc, ctx, path, synth["tex"], 320, 192, 1, 31 + tree, mode=2, kernel=kernel)
+                _assert_frames(g, r, "%s wide_tree %d kernel %d" % (scene, tree, kernel))
+                assert stats["rays"] == rc["rays"] and stats["shades"] == rc["S"]
+            visits[tree] = (stats["node_visits"] / stats["rays"], ctx.get_option("wide_own_bounds"))
+        print("   %s: records per ray %.2f over own bounds (%d triangles), %.2f over the leaf boxes" % (scene, visits[2][0], visits[2][1], visits[1][0]))
+        assert visits[1][1] == 0
+        if visits[2][1] > 0: assert visits[2][0] < visits[1][0]
+        if scene == "hf_small.rts/10": assert visits[2][1] > 9000
+    finally:
+        ctx.set_option("wide_tree", 2)
+
+
 @pytest.mark.parametrize("kernel,mode", [(0, 0), (1, 0), (1, 2)])
 def test_spp_and_aperture(dr, orc, ctx, synth, tmp_path, kernel, mode):
     """spp > 1 inside one launch (per-sample reseed, K:1059-1065) and a wide lens (K:1071-1073)."""

@@ -122,6 +122,18 @@ long long hk_check_reject(long long n, unsigned long long seed, double* max_d2_g
   return bad;
 }
 
+// device_core.hpp wide_ray_margin, for the test of its lemma (tests/test_margin_lemma.py): the position margin of n rays for the scene constants (e, l, v)
+void hk_ray_margin(long long n, const float* o, const float* d, float e, float l, float v, float* out) {
+  const WideMu mu = {e, l, v};
+  for (long long i = 0; i < n; i++) out[i] = wide_ray_margin(mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), mu);
+}
+// hit_tri (device_core.hpp tri_hit) on n ray / triangle pairs: t or -1
+void hk_tri_hit(long long n, const float* o, const float* d, const float* v0, const float* e1, const float* e2, float* t) {
+  for (long long i = 0; i < n; i++)
+    t[i] = tri_hit(mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), mk(v0[3 * i], v0[3 * i + 1], v0[3 * i + 2]),
+                   mk(e1[3 * i], e1[3 * i + 1], e1[3 * i + 2]), mk(e2[3 * i], e2[3 * i + 1], e2[3 * i + 2]));
+}
+
 const char* hk_last_error() { return hk_err.c_str(); }
 
 void* hk_scene_load(const char* rts_path, const char* texdir) {

@@ -40,6 +40,10 @@ def lib():
         L.hk_wide_depth.argtypes = [C.c_void_p]
         L.hk_check_uniform.restype = C.c_longlong
         L.hk_check_uniform.argtypes = [C.c_longlong, C.c_ulonglong]
+        L.hk_ray_margin.restype = None
+        L.hk_ray_margin.argtypes = [C.c_longlong, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.hk_tri_hit.restype = None
+        L.hk_tri_hit.argtypes = [C.c_longlong] + [C.c_void_p] * 6
         L.hk_check_reject.restype = C.c_longlong
         L.hk_check_reject.argtypes = [C.c_longlong, C.c_ulonglong, C.POINTER(C.c_double)]
         L.hk_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
