@@ -610,18 +610,18 @@ __device__ __forceinline__ WideRay wide_ray_none() {      // a lane without a ra
 // Above the cap the margin is the reference's own padding (B + 0.01 (1 + 2^-16) + the absolute term encloses the padded box): such rays -- camera rays with a
 // long direction vector, mostly -- walk the tree exactly as they would the tree over padded boxes.  Rays or scenes beyond 2^30 take the cap too (no overflow
 // inside the bound's arithmetic below that).
-__device__ __forceinline__ float wide_ray_margin(V3 o, V3 d, WideMu mu) {
-  if (!(mu.e > 0.0f)) return 0.0f;
-  const float abs_term = (__builtin_sqrtf(dot(o, o)) * 1.0001f + mu.v + 4.0f * mu.l + 1.0f) * 0x1p-21f;
+__device__ __forceinline__ float wide_ray_margin(V3 o, V3 d, float mu_e, float mu_l, float mu_v) {
+  if (!(mu_e > 0.0f)) return 0.0f;
+  const float abs_term = (__builtin_sqrtf(dot(o, o)) * 1.0001f + mu_v + 4.0f * mu_l + 1.0f) * 0x1p-21f;
   const float cap = 0.01f * (1.0f + 0x1p-16f) + abs_term;
-  const float dn = __builtin_sqrtf(dot(d, d)) * 1.0001f, s = __builtin_sqrtf(dot(o, o)) * 1.0001f + mu.v;
-  const float m = dn * mu.e * 1.0001f * (0.021f * s + 0.015f * mu.l + 1.2e-4f) * 1.0001f + abs_term;
-  const bool tame = dn <= 0x1p30f && s <= 0x1p30f && dn * mu.e <= 2.0f;      // (false for NaNs)
+  const float dn = __builtin_sqrtf(dot(d, d)) * 1.0001f, s = __builtin_sqrtf(dot(o, o)) * 1.0001f + mu_v;
+  const float m = dn * mu_e * 1.0001f * (0.021f * s + 0.015f * mu_l + 1.2e-4f) * 1.0001f + abs_term;
+  const bool tame = dn <= 0x1p30f && s <= 0x1p30f && dn * mu_e <= 2.0f;      // (false for NaNs)
   return (tame && m < cap) ? m : cap;
 }
-__device__ __forceinline__ WideRay wide_ray(V3 o, V3 d, V3 inv, float pmax, WideMu mu) {
+__device__ __forceinline__ WideRay wide_ray(V3 o, V3 d, V3 inv, float pmax, float mu_e, float mu_l, float mu_v) {      // (mu_*: the scene's WideMu)
   WideRay w;
-  const float extra = wide_ray_margin(o, d, mu);
+  const float extra = wide_ray_margin(o, d, mu_e, mu_l, mu_v);
   auto one = [pmax, extra](float oa, float ia, float& ic, float& on, float& of) {
     ic = __builtin_fminf(__builtin_fmaxf(ia, -0x1p60f), 0x1p60f);                    // NaN -> -2^60, and the margin below is NaN
     const float k = __builtin_fmaf(pmax + __builtin_fabsf(oa), 0x1p-21f, 0x1p-40f) + extra;
@@ -814,12 +814,12 @@ __device__ __forceinline__ void wide_leaf_compute(const WideRec& r, V3 o, V3 d, 
   wide_leaf_compute<COUNT>(r, o, d, inv, sg, tr, ws, stack, c);
 }
 template <bool COUNT>
-__device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, float pmax, WideMu mu, V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [word * 64] */) {
+__device__ __forceinline__ Hit closest_hit_wide(WalkRsrc wide, float pmax, float mu_e, float mu_l, float mu_v, V3 o, V3 d, Ctr& c, int* __restrict__ stack /* [word * 64] */) {
   Trav tr;
   trav_begin(tr);
   WideStack ws; ws.top = 0u; ws.sp = 0; ws.sb = 0;
   const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  const WideRay wr = wide_ray(o, d, inv, pmax, mu);
+  const WideRay wr = wide_ray(o, d, inv, pmax, mu_e, mu_l, mu_v);
   if (COUNT) c.rays++;
   while (tr.node >= 0) {
     const WideRec r = wide_fetch(wide, tr.node);

@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, OCC) void trace_probe_kernel(RenderParams P, c
             const float4 a = rays[2 * (size_t)my], b = rays[2 * (size_t)my + 1];
             idx = my; o = mk(a.x, a.y, a.z); d = mk(b.x, b.y, b.z);
             inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-            wr = wide_ray(o, d, inv, P.wide_pmax, P.wide_mu); sg = sign_mask(inv);
+            wr = wide_ray(o, d, inv, P.wide_pmax, P.wide_mu.e, P.wide_mu.l, P.wide_mu.v); sg = sign_mask(inv);
             trav_begin(tr); ws.top = 0u; ws.sp = 0; ws.sb = 0;
           } else tr.node = my >= n ? -3 : -2;      // (-2: the chunk ran out in the middle of the wave's request: next refill)
         }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void trace_plain_kernel(RenderParams P, const 
   int* const stack = lds + (threadIdx.x >> 6) * (WIDE_STACK * 64) + (threadIdx.x & 63);
   Ctr c = {0, 0, 0, 0, 0, 0, 0, 0};
   const float4 a = rays[2 * (size_t)i], b = rays[2 * (size_t)i + 1];
-  const Hit h = closest_hit_wide<false>(wide_rsrc(P), P.wide_pmax, P.wide_mu, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), c, stack);
+  const Hit h = closest_hit_wide<false>(wide_rsrc(P), P.wide_pmax, P.wide_mu.e, P.wide_mu.l, P.wide_mu.v, mk(a.x, a.y, a.z), mk(b.x, b.y, b.z), c, stack);
   out[i] = h.slot < 0 ? make_uint2(__float_as_uint(10000.0f), 0xffffffffu) : make_uint2(__float_as_uint(h.t), (unsigned)h.slot);
 }
 
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void kat_hit_kernel(RenderParams P, int n, con
     h = closest_hit_ordered<true>(P.pairs, P.prims, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
   } else if (MODE == DR_TRAVERSAL_WIDE) {
     int* stack = lds_stack + (threadIdx.x >> 6) * (WIDE_STACK * 64) + (threadIdx.x & 63);
-    h = closest_hit_wide<true>(wide_rsrc(P), P.wide_pmax, P.wide_mu, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
+    h = closest_hit_wide<true>(wide_rsrc(P), P.wide_pmax, P.wide_mu.e, P.wide_mu.l, P.wide_mu.v, ld3(o + 3 * i), ld3(d + 3 * i), c, stack);
   } else {
     h = closest_hit_threaded<true>(walk_rsrc(P), ld3(o + 3 * i), ld3(d + 3 * i), c);
   }

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(256, OCC) void render_kernel(RenderParams P) {
     } else if (MODE == DR_TRAVERSAL_WIDE) {
       const WalkRsrc wide = wide_rsrc(P);
       int* stack = lds_stack + wave * (WIDE_STACK * 64) + lane;
-      auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_wide<COUNT>(wide, P.wide_pmax, P.wide_mu, o, d, cc, stack); };
+      auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_wide<COUNT>(wide, P.wide_pmax, P.wide_mu.e, P.wide_mu.l, P.wide_mu.v, o, d, cc, stack); };
       render_pixel<COUNT>(P, closest, x, y, c);
     } else {
       const WalkRsrc walk = walk_rsrc(P);
@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
         color = mk(0, 0, 0); px = -1; py = 0; pcode = 0; sample = 0; frame = 0;
         if (fresh_ray) { ws.top = 0u; ws.sp = 0; ws.sb = 0; }
         inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);      // 1/direction and the folded test's margins are
-        wr = wide_ray(path.rayo, path.raydir, inv, P.wide_pmax, P.wide_mu);                // recomputed for every lane rather than stashed
+        wr = wide_ray(path.rayo, path.raydir, inv, P.wide_pmax, P.wide_mu.e, P.wide_mu.l, P.wide_mu.v);                // recomputed for every lane rather than stashed
         sg = sign_mask(inv);
       } else {
         asm volatile("" ::: "memory");
@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256, OCC) void render_persistent_kernel(RenderParam
           ws.top = (unsigned)xch[rank_i + 6 * XCH_MAX]; ws.sp = 0; ws.sb = 0;
           share = xch[rank_i + 7 * XCH_MAX];
           inv = mk(1.0f / path.raydir.x, 1.0f / path.raydir.y, 1.0f / path.raydir.z);
-          wr = wide_ray(path.rayo, path.raydir, inv, P.wide_pmax, P.wide_mu);
+          wr = wide_ray(path.rayo, path.raydir, inv, P.wide_pmax, P.wide_mu.e, P.wide_mu.l, P.wide_mu.v);
           sg = sign_mask(inv);
           const unsigned long long k = share_key[share];
           tr.best_t = __uint_as_float((unsigned)(k >> 32)); tr.best_slot = (int)(unsigned)k;

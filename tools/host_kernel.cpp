@@ -40,7 +40,7 @@ void render_columns(const RenderParams& P, int traversal, int first, int step, C
       for (int lane = 0; lane < 64; lane++) {                       // lane l of a tile is pixel (l >> 3, l & 7), as in the kernels
         const int x = bx * 8 + (lane >> 3), y = by * 8 + (lane & 7);
         if (traversal == DR_TRAVERSAL_WIDE && P.wide) {
-          auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_wide<COUNT>(wide, P.wide_pmax, P.wide_mu, o, d, cc, stack.data()); };
+          auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_wide<COUNT>(wide, P.wide_pmax, P.wide_mu.e, P.wide_mu.l, P.wide_mu.v, o, d, cc, stack.data()); };
           render_pixel<COUNT>(P, closest, x, y, c);
         } else if (traversal == DR_TRAVERSAL_ORDERED) {
           auto closest = [&](V3 o, V3 d, Ctr& cc) { return closest_hit_ordered<COUNT>(P.pairs, P.prims, o, d, cc, stack.data()); };
@@ -124,8 +124,7 @@ long long hk_check_reject(long long n, unsigned long long seed, double* max_d2_g
 
 // device_core.hpp wide_ray_margin, for the test of its lemma (tests/test_margin_lemma.py): the position margin of n rays for the scene constants (e, l, v)
 void hk_ray_margin(long long n, const float* o, const float* d, float e, float l, float v, float* out) {
-  const WideMu mu = {e, l, v};
-  for (long long i = 0; i < n; i++) out[i] = wide_ray_margin(mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), mu);
+  for (long long i = 0; i < n; i++) out[i] = wide_ray_margin(mk(o[3 * i], o[3 * i + 1], o[3 * i + 2]), mk(d[3 * i], d[3 * i + 1], d[3 * i + 2]), e, l, v);
 }
 // hit_tri (device_core.hpp tri_hit) on n ray / triangle pairs: t or -1
 void hk_tri_hit(long long n, const float* o, const float* d, const float* v0, const float* e1, const float* e2, float* t) {

@@ -37,7 +37,7 @@ struct WideStats { long nodes = 0, leaves = 0, tests = 0, maxsp = 0, cull_nodes 
 
 static void wide_hit(const std::vector<DevUnit>& rec, float pmax, WideMu mu, const float o[3], const float d[3], const float inv[3], float& best_t, int& best_slot, WideStats& ws) {
   best_t = 10000.0f; best_slot = -1;      // trav_begin
-  const WideRay wr = wide_ray(mk(o[0], o[1], o[2]), mk(d[0], d[1], d[2]), mk(inv[0], inv[1], inv[2]), pmax, mu);
+  const WideRay wr = wide_ray(mk(o[0], o[1], o[2]), mk(d[0], d[1], d[2]), mk(inv[0], inv[1], inv[2]), pmax, mu.e, mu.l, mu.v);
   unsigned stack[WIDE_STACK]; int sp = 0; unsigned top = 0;
   float sd[WIDE_STACK + 1][4]; float topd[4] = {0, 0, 0, 0};   // study only: entry distance of every pending child
   unsigned cur = 0;   // index << 1 | leaf
