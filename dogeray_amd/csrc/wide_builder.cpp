@@ -287,7 +287,28 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
       const DevPrim& p = prims[(size_t)s];
       if (p.type == 2) vmax_all = std::max(vmax_all, std::sqrt((double)p.v0[0] * p.v0[0] + (double)p.v0[1] * p.v0[1] + (double)p.v0[2] * p.v0[2]));
     }
-    const double e_cut = 0.003 / (0.021 * (2.0 * vmax_all + 1.0)), l_cut = std::max(1.0, vmax_all);
+    // The cut: the rays' margin is a multiple of the LARGEST |e1| |e2| that gets in, so one medium triangle taxes every small one.  Of the values of |e1| |e2|
+    // in the scene (a sample of them), take the one that maximises (triangles at or below it) x (padding it leaves them: 0.01 minus a unit ray's margin).
+    const double s_ref = 2.0 * vmax_all + 1.0, l_cut = std::max(1.0, vmax_all);
+    double e_cut = 0;
+    {
+      std::vector<double> es;
+      es.reserve((size_t)N);
+      for (int s = 0; s < N; s++) {
+        const DevPrim& p = prims[(size_t)s];
+        if (p.type != 2) continue;
+        const double n1 = std::sqrt((double)p.e1x * p.e1x + (double)p.e1y * p.e1y + (double)p.e1z * p.e1z), n2 = std::sqrt((double)p.e2x * p.e2x + (double)p.e2y * p.e2y + (double)p.e2z * p.e2z);
+        if (n1 * n2 == n1 * n2 && n1 + n2 <= l_cut) es.push_back(n1 * n2);
+      }
+      std::sort(es.begin(), es.end());
+      double best = 0;
+      for (int q = 1; q <= 64 && !es.empty(); q++) {
+        const size_t k = std::min(es.size() - 1, es.size() * (size_t)q / 64);
+        const double e = es[k], left = 0.01 - 0.021 * e * s_ref;
+        const size_t count = (size_t)(std::upper_bound(es.begin(), es.end(), e) - es.begin());
+        if (left > 0 && (double)count * left > best) { best = (double)count * left; e_cut = e; }
+      }
+    }
     double e_s = 0, l_s = 0, v_s = 0;
     int chosen = 0;
     if (vmax_all < 0x1p30) {
