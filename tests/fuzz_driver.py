@@ -21,7 +21,8 @@ def run_campaign(dr, orc, ctx, n_scenes, seed, workdir, texdir, texture_names, s
         for k in range(n_scenes):
             W = int(rng.choice(sizes or [64, 96, 100, 131, 200, 320])); H = int(rng.choice(sizes or [40, 64, 75, 128, 192]))
             nobj = int(rng.integers(2, 1500))
-            path = random_scene(rng, nobj, os.path.join(workdir, "f%d.rts" % k), W=W, H=H, textures=texture_names)
+            scale = float(rng.choice([1.0, 1.0, 0.2, 0.05, 0.02]))      # (small scenes: triangles the size of the reference's padding, entered with their own bounds)
+            path = random_scene(rng, nobj, os.path.join(workdir, "f%d.rts" % k), W=W, H=H, textures=texture_names, scale=scale)
             ps = dr.Scene.load(path, texdir); ps.build_bvh()
             osc = orc.Scene(path, texdir); osc.build_bvh()
             ctx.set_option("wide_tree", int(rng.choice([2, 2, 2, 1, 0])))      # (read at upload)

@@ -6,27 +6,29 @@ def fmt(x):
     return "%f" % x
 
 
-def random_scene(rng, n, path, W=96, H=64, textures=(), spheres=True, duplicates=True, degenerate=True):
+def random_scene(rng, n, path, W=96, H=64, textures=(), spheres=True, duplicates=True, degenerate=True, scale=1.0):
     """Writes a scene with n objects: triangles with random column counts (16..38), spheres, every material,
-    exact duplicates (equal-t ties), degenerate and axis-aligned triangles, shared vertices."""
+    exact duplicates (equal-t ties), degenerate and axis-aligned triangles, shared vertices.
+    scale: every position, radius and the focus distance times this (the reference pads leaf boxes by an ABSOLUTE 0.01: a scene a fiftieth of the size has
+    triangles as small as the padding, and the wide tree enters them with their own bounds -- wide_tree = 2)."""
     lines = []
-    cam = rng.uniform(-1, 1, 3) * 0.5 + np.array([0, -1.0, 6.0])
+    cam = (rng.uniform(-1, 1, 3) * 0.5 + np.array([0, -1.0, 6.0])) * scale
     depth = int(rng.integers(1, 7))
     spp = int(rng.integers(1, 3))
     env = "no"
     if textures and rng.random() < 0.5:
         env = textures[int(rng.integers(0, len(textures)))]
     lines.append("*," + ",".join(fmt(v) for v in cam) + ",%f,0,0,0,%f,%d,%d,%d,%f,%s,%d,%d" % (
-        rng.choice([0.0, 0.01, 0.3]), rng.uniform(3, 8), int(rng.integers(30, 70)), depth, spp, rng.uniform(0.3, 1.2), env, W, H))
+        rng.choice([0.0, 0.01, 0.3]) * scale, rng.uniform(3, 8) * scale, int(rng.integers(30, 70)), depth, spp, rng.uniform(0.3, 1.2), env, W, H))
     objs = []
     while len(objs) < n:
         r = rng.random()
         if spheres and r < 0.15:
-            c = rng.uniform(-2.5, 2.5, 3)
+            c = rng.uniform(-2.5, 2.5, 3) * scale
             mat = int(rng.choice([0, 1, 2, 3, 4, 5]))
             cols = rng.uniform(0.1, 1.0, 3) if mat != 1 else rng.uniform(1, 5, 3)
             objs.append(",".join([fmt(c[0]), fmt(c[1]), fmt(c[2]), "0", fmt(cols[0]), fmt(cols[1]), fmt(cols[2]),
-                                  fmt(rng.choice([0.0, 0.2, 1.5])), "0", fmt(rng.uniform(0.2, 0.9)), "0", "0", str(mat)]))
+                                  fmt(rng.choice([0.0, 0.2, 1.5])), "0", fmt(rng.uniform(0.2, 0.9) * scale), "0", "0", str(mat)]))
             continue
         v0 = rng.uniform(-3, 3, 3)
         if degenerate and r < 0.2:
@@ -36,6 +38,7 @@ def random_scene(rng, n, path, W=96, H=64, textures=(), spheres=True, duplicates
             v1, v2 = v0 + np.array([2.0, 0, 0]), v0 + np.array([0, 0, 2.0])
         else:
             v1, v2 = v0 + rng.uniform(-1.5, 1.5, 3), v0 + rng.uniform(-1.5, 1.5, 3)
+        v0, v1, v2 = v0 * scale, v1 * scale, v2 * scale
         mat = int(rng.choice([0, 0, 0, 1, 2, 3, 4, 5]))
         col = rng.uniform(0.1, 1.0, 3) if mat != 1 else rng.uniform(1, 4, 3)
         add_y = 1.5 if mat == 4 else float(rng.choice([0.0, 0.1, 0.5]))

@@ -51,6 +51,8 @@ def test_host_build_of_the_kernel_renders_like_the_oracle(hk, orc, synth, tmp_pa
              (os.path.join(SCENES, "rough.blend.rts"), synth["tex"], 160, 96, 1), (os.path.join(SCENES, "cow.rts"), synth["tex"], 160, 96, 1),
              (os.path.join(synth["dir"], "matball.rts"), synth["tex"], 128, 128, 1), (os.path.join(synth["dir"], "hf_small.rts"), "", 160, 96, 1)]
     cases += [(random_scene(rng, int(rng.integers(2, 500)), str(tmp_path / ("hk%d.rts" % k)), W=96, H=64, textures=names), synth["tex"], 96, 64, 1) for k in range(5)]
+    # scenes a twentieth / a fiftieth of the size: triangles as small as the reference's 0.01 padding, which the wide tree enters with their own bounds
+    cases += [(random_scene(rng, int(rng.integers(50, 600)), str(tmp_path / ("hks%d.rts" % k)), W=96, H=64, textures=names, scale=(0.05, 0.02, 0.2)[k]), synth["tex"], 96, 64, 1) for k in range(3)]
     for path, tex, W, H, div in cases:
         got, gc, want, wc = _both(hk, orc, path, tex, W, H, div, 4242, traversal)
         same = float(np.all(got == want, axis=2).mean())
