@@ -278,7 +278,8 @@ bool build_wide(const HostScene& sc, const std::vector<int>& leaf_node_of_slot, 
   // ---- 0. the boxes the tree is built over and culls with.  tree_mode 2: a small triangle enters with its OWN bounds (the record's v0, v0 + e1, v0 + e2,
   // rounded outward) instead of the reference's leaf box, which is those bounds padded by 0.01 (K:353-354) -- 2.9 times the footprint of a 0.028-wide triangle --;
   // the rays make up for it with a margin that is a multiple of E = max |e1| |e2| over these triangles (device_core.hpp wide_ray_margin).
-  // "Small": the margin of a unit-length ray from anywhere in the scene stays below 0.003.  Other primitives keep the reference's box.
+  // "Small": |e1| |e2| at or below a cut chosen per scene (below); the tree keeps the reference's boxes altogether unless at least half of the leaves qualify.
+  // Other primitives keep the reference's box.
   std::vector<Box> cull(leaf);
   out.mu = WideMu{0, 0, 0}; out.own_bounds = 0;
   if (tree_mode == 2) {
