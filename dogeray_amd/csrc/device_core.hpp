@@ -612,9 +612,9 @@ __device__ __forceinline__ WideRay wide_ray_none() {      // a lane without a ra
 // inside the bound's arithmetic below that).
 __device__ __forceinline__ float wide_ray_margin(V3 o, V3 d, float mu_e, float mu_l, float mu_v) {
   if (!(mu_e > 0.0f)) return 0.0f;
-  const float abs_term = (__builtin_sqrtf(dot(o, o)) * 1.0001f + mu_v + 4.0f * mu_l + 1.0f) * 0x1p-21f;
+  const float on = __builtin_sqrtf(dot(o, o)) * 1.0001f, dn = __builtin_sqrtf(dot(d, d)) * 1.0001f, s = on + mu_v;
+  const float abs_term = (s + 4.0f * mu_l + 1.0f) * 0x1p-21f;
   const float cap = 0.01f * (1.0f + 0x1p-16f) + abs_term;
-  const float dn = __builtin_sqrtf(dot(d, d)) * 1.0001f, s = __builtin_sqrtf(dot(o, o)) * 1.0001f + mu_v;
   const float m = dn * mu_e * 1.0001f * (0.021f * s + 0.015f * mu_l + 1.2e-4f) * 1.0001f + abs_term;
   const bool tame = dn <= 0x1p30f && s <= 0x1p30f && dn * mu_e <= 2.0f;      // (false for NaNs)
   return (tame && m < cap) ? m : cap;
