@@ -630,7 +630,9 @@ void launch_tile_kernel(hipStream_t stream, const RenderParams& P, int traversal
 
 namespace {
 
-template <int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL = 1>
+// (COOP_PARK, COOP_UNROLL: the work-sharing build's own leaf-step threshold and steps per iteration -- short launches like fewer lanes per leaf step and more
+// steps between two looks at the queue: 32 / 12 / 4 against the lean build's 32 / 20 / 2, one frame per launch 0.915 against 0.945 ms, profiles/r4_q_short_launch_schedule.txt)
+template <int OCC, int TRAV_MIN, int PARK_MIN, int P_UNROLL = 1, int COOP_PARK = PARK_MIN, int COOP_UNROLL = P_UNROLL>
 int launch_persistent(hipStream_t stream, const RenderParams& P_in, const PersistentCfg& cfg, unsigned* counter, const int* order, const int* rstart, unsigned* pixel_cost) {
   RenderParams P = P_in;
   int work = P.ncols * P.gy * P.batch;
@@ -644,7 +646,7 @@ int launch_persistent(hipStream_t stream, const RenderParams& P_in, const Persis
     const bool coop = P.coop_steps > 0 && (long long)work < (long long)cfg.coop_tiles_per_wave * blocks * 4;
     if (!coop) log_waves = 0;      // only the work-sharing build writes the log
     if (cfg.count) hipLaunchKernelGGL((render_persistent_kernel<true, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, false>), grid, block, 0, stream, P, counter, order, rstart, pixel_cost);
-    else if (coop) hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, true>), grid, block, 0, stream, P, counter, order, rstart, pixel_cost);
+    else if (coop) hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, COOP_PARK, COOP_UNROLL, true, true>), grid, block, 0, stream, P, counter, order, rstart, pixel_cost);
     else hipLaunchKernelGGL((render_persistent_kernel<false, OCC, TRAV_MIN, PARK_MIN, P_UNROLL, true, false>), grid, block, 0, stream, P, counter, order, rstart, pixel_cost);
     return log_waves;
   }
@@ -670,12 +672,12 @@ bool launch_wide_lean6(hipStream_t stream, const RenderParams& P_in, const Persi
 }
 
 // The instantiated schedules (option "schedule"): 0 = the tuned one -- shade / refill below 32 walking lanes, leaf steps for 20 lanes, two steps per
-// loop iteration --; 1 and 2 keep the other paths of the loop alive in the tests (leaf steps for 8 lanes, one step per iteration; shade / refill
+// loop iteration (work-sharing build: 12 lanes, four steps) --; 1 and 2 keep the other paths of the loop alive in the tests (leaf steps for 8 lanes, one step per iteration; shade / refill
 // below 48 lanes, leaves tested on the spot).  Every other combination rounds 2 and 3 measured is in profiles/r2_*, r3_p_*.
 template <int OCC>
 int launch_persistent_occ(hipStream_t stream, const RenderParams& P, const PersistentCfg& cfg, unsigned* counter, const int* order, const int* rstart, unsigned* pcost) {
   switch (cfg.schedule) {
-    case 0:  return launch_persistent<OCC, 32, 20, 2>(stream, P, cfg, counter, order, rstart, pcost);
+    case 0:  return launch_persistent<OCC, 32, 20, 2, 12, 4>(stream, P, cfg, counter, order, rstart, pcost);
     case 1:  return launch_persistent<OCC, 32, 8, 1>(stream, P, cfg, counter, order, rstart, pcost);
     default: return launch_persistent<OCC, 48, 0, 1>(stream, P, cfg, counter, order, rstart, pcost);
   }
@@ -700,7 +702,7 @@ int launch_persistent_kernel(hipStream_t stream, const RenderParams& P, const Pe
     if (blocks * 4 > work) blocks = (work + 3) / 4;
     RenderParams Q = P;
     if (Q.wave_log && blocks * 4 > WAVE_LOG_WAVES) Q.wave_log = nullptr;
-    hipLaunchKernelGGL((render_persistent_kernel<false, 5, 32, 20, 2, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, Q, tile_counter, order, rstart, pixel_cost);
+    hipLaunchKernelGGL((render_persistent_kernel<false, 5, 32, 12, 4, true, true, true>), dim3((unsigned)blocks), dim3(256), 0, stream, Q, tile_counter, order, rstart, pixel_cost);
     return Q.wave_log ? blocks * 4 : 0;
   }
   if (cfg.occupancy >= 6 && launch_wide_lean6(stream, P, cfg, tile_counter, order, rstart, pixel_cost, log_waves)) return log_waves;

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 FAST = {"v_fma_f32", "v_fmac_f32", "v_mul_f32", "v_add_f32", "v_sub_f32", "v_subrev_f32", "v_or_b32", "v_and_b32", "v_xor_b32", "v_bitop3_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32",
         "v_mov_b32", "v_lshrrev_b32", "v_not_b32", "v_mac_f32", "v_madak_f32", "v_madmk_f32", "v_fmaak_f32", "v_fmamk_f32", "v_accvgpr_read_b32", "v_accvgpr_write_b32", "v_add_co_u32", "v_addc_co_u32"}
 TRANS = {"v_rcp_f32", "v_sqrt_f32", "v_rsq_f32", "v_rcp_f64", "v_sqrt_f64", "v_rsq_f64", "v_exp_f32", "v_log_f32", "v_sin_f32", "v_cos_f32"}
-KERNELS = (("_ZN2dr24render_persistent_kernelILb0ELi6ELi32ELi20ELi2ELb1ELb0ELb0EE", "lean (6 waves/SIMD)"), ("_ZN2dr24render_persistent_kernelILb0ELi5ELi32ELi20ELi2ELb1ELb1ELb0EE", "work-sharing (5 waves/SIMD)"))
+KERNELS = (("_ZN2dr24render_persistent_kernelILb0ELi6ELi32ELi20ELi2ELb1ELb0ELb0EE", "lean (6 waves/SIMD)"), ("_ZN2dr24render_persistent_kernelILb0ELi5ELi32ELi12ELi4ELb1ELb1ELb0EE", "work-sharing (5 waves/SIMD)"))
 
 def cost(op):
     base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", op)
